@@ -1,0 +1,81 @@
+"""ctypes loader for libmi355clip.so (include/mi355clip.h).
+
+There is no fallback: if the library is missing or a call fails, this raises.
+Loading the library and resolving symbols needs no GPU; creating a handle does.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmi355clip.so")
+
+c_f = ctypes.POINTER(ctypes.c_float)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_vp = ctypes.c_void_p
+
+# every symbol include/mi355clip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "mi_last_error": (ctypes.c_char_p, []),
+    "mi_abi_version": (ctypes.c_int, []),
+    "mi_device_count": (ctypes.c_int, []),
+    "mi_clip_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "mi_clip_free": (None, [c_vp]),
+    "mi_clip_info": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint32)]),
+    "mi_clip_embed": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "mi_clip_embed_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp]),
+    "mi_clip_embed_rgb8": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "mi_preprocess_rgb8": (ctypes.c_int, [c_vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, c_vp]),
+    "mi_knn_create": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "mi_knn_free": (None, [c_vp]),
+    "mi_knn_set_base": (ctypes.c_int, [c_vp, ctypes.c_uint64]),
+    "mi_knn_reserve": (ctypes.c_int, [c_vp, ctypes.c_uint64]),
+    "mi_knn_size": (ctypes.c_int, [c_vp, c_u64p]),
+    "mi_knn_append": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint64]),
+    "mi_knn_append_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint64, c_vp]),
+    "mi_knn_append_synthetic": (ctypes.c_int, [c_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]),
+    "mi_knn_get_rows": (ctypes.c_int, [c_vp, ctypes.c_uint64, ctypes.c_uint64, c_vp]),
+    "mi_knn_search": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
+    "mi_knn_search_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp]),
+    "mi_knn_search_batched_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp]),
+    "mi_knn_merge": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
+    "mi_average_slices": (ctypes.c_int, [ctypes.POINTER(c_f), ctypes.c_size_t, ctypes.c_size_t, c_f]),
+    "mi_refine": (ctypes.c_int, [c_f, ctypes.POINTER(c_f), ctypes.c_size_t, ctypes.c_size_t, c_f]),
+}
+
+MI_OK = 0
+ERR_NAMES = {-1: "MI_ERR_INVALID", -2: "MI_ERR_IO", -3: "MI_ERR_HIP", -4: "MI_ERR_NO_DEVICE",
+             -5: "MI_ERR_UNSUPPORTED", -6: "MI_ERR_OOM"}
+
+
+class MiError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library; raises (loudly) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -m image_search_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != MI_OK:
+        raise MiError(rc, lib().mi_last_error().decode(errors="replace"))

@@ -1,0 +1,74 @@
+// common.h — error plumbing shared by the C-ABI translation units of libmi355clip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/mi355clip.h"
+
+namespace mi {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string& m);
+
+[[noreturn]] inline void fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error(code, buf);
+}
+
+inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
+    if (e != hipSuccess) {
+        int code = (e == hipErrorOutOfMemory) ? MI_ERR_OOM : MI_ERR_HIP;
+        fail(code, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    }
+}
+#define HIP_CHECK(x) ::mi::hip_check((x), #x, __FILE__, __LINE__)
+
+// Every extern "C" body runs inside this: nothing may unwind across the ABI.
+template <class F>
+int guarded(F&& f) noexcept {
+    try {
+        f();
+        return MI_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("host allocation failed");
+        return MI_ERR_OOM;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return MI_ERR_INVALID;
+    } catch (...) {
+        set_last_error("unknown error");
+        return MI_ERR_INVALID;
+    }
+}
+
+// Select `device` and require it to be a gfx950 part: there is no fallback path.
+void use_device(int device);
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int device) {
+        (void)hipGetDevice(&prev);
+        use_device(device);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace mi

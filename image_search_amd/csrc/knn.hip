@@ -1,0 +1,363 @@
+// knn.hip — host side of Seam B behind the C ABI (include/mi355clip.h).
+// One mi_knn = one row-shard of the reference's `image.embedding` column
+// (server/src/search.rs:13-18) resident in HBM on one GPU.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "knn_kernels.h"
+
+using namespace mi;
+
+struct mi_knn {
+    int device = 0;
+    uint32_t dim = 0;
+    uint64_t base = 0, rows = 0, cap = 0;
+    float* table = nullptr;
+    hipStream_t stream = nullptr;
+    int n_cu = 0;
+    // search workspace
+    float* d_q = nullptr;        // [16][dim]
+    uint64_t* d_cand = nullptr;  // per-wave lists
+    uint64_t* d_tmp = nullptr;   // merge level output
+    uint64_t* d_keys = nullptr;  // final keys (k rounded up to 1024 multiples)
+    uint64_t* d_idx = nullptr;
+    float* d_dist = nullptr;
+    size_t cand_keys = 0, tmp_keys = 0, keys_cap = 0, idx_cap = 0, dist_cap = 0;
+    std::mutex mu;
+};
+
+namespace {
+
+constexpr int MAX_BATCH_Q = 8;
+
+void ensure(void** p, size_t* have, size_t want, size_t elem) {
+    if (*have >= want) return;
+    if (*p) HIP_CHECK(hipFree(*p));
+    *p = nullptr; *have = 0;
+    HIP_CHECK(hipMalloc(p, want * elem));
+    *have = want;
+}
+
+void grow(mi_knn* t, uint64_t want_rows) {
+    if (want_rows <= t->cap) return;
+    uint64_t ncap = std::max<uint64_t>(want_rows, t->cap + t->cap / 2);
+    ncap = (ncap + 63) & ~63ull;
+    if (ncap > 0xFFFFFFFFull) fail(MI_ERR_UNSUPPORTED, "a shard holds at most 2^32-1 rows (asked %llu)",
+                                    (unsigned long long)want_rows);
+    float* nt = nullptr;
+    HIP_CHECK(hipMalloc((void**)&nt, ncap * t->dim * sizeof(float)));
+    if (t->rows) {
+        HIP_CHECK(hipMemcpyAsync(nt, t->table, t->rows * t->dim * sizeof(float), hipMemcpyDeviceToDevice, t->stream));
+        HIP_CHECK(hipStreamSynchronize(t->stream));
+    }
+    if (t->table) HIP_CHECK(hipFree(t->table));
+    t->table = nt;
+    t->cap = ncap;
+}
+
+template <class K>
+void allow_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+template <class Top>
+void launch_scan(mi_knn* t, const float* d_q, uint32_t k, const uint64_t* lo, uint64_t* cand, uint32_t blocks,
+                 hipStream_t s) {
+    const size_t lds = (size_t)4 * Top::LDS_KEYS * sizeof(uint64_t);
+    switch (t->dim / 64) {
+#define MI_CASE(NCH)                                                                                   \
+    case NCH:                                                                                          \
+        allow_lds(knn_scan_kernel<NCH, Top>, lds);                                                     \
+        hipLaunchKernelGGL((knn_scan_kernel<NCH, Top>), dim3(blocks), dim3(256), lds, s, t->table,     \
+                           t->rows, d_q, k, lo, cand);                                                 \
+        break;
+        MI_CASE(1) MI_CASE(2) MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16)
+#undef MI_CASE
+        default: fail(MI_ERR_UNSUPPORTED, "dim %u: built for dim/64 in {1,2,4,8,12,16}", t->dim);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+template <class Top>
+void launch_merge(const uint64_t* in, uint32_t n_lists, uint32_t k, uint32_t lpb, uint64_t* out, uint32_t nq,
+                  size_t in_stride, size_t out_stride, hipStream_t s) {
+    const size_t lds = (size_t)4 * Top::LDS_KEYS * sizeof(uint64_t);
+    allow_lds(knn_merge_kernel<Top>, lds + 4096);
+    const uint32_t blocks = (n_lists + lpb - 1) / lpb;
+    hipLaunchKernelGGL((knn_merge_kernel<Top>), dim3(blocks, nq), dim3(256), lds, s, in, n_lists, k, lpb, out,
+                       in_stride, out_stride);
+    HIP_CHECK(hipGetLastError());
+}
+
+// One pass: the kp <= 1024 smallest keys (> *lo if lo) of the shard, ascending, into keys_out[0..kp).
+template <class Top>
+void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint64_t* keys_out, hipStream_t s) {
+    const uint32_t bpc = Top::LDS_KEYS == 0 ? 4 : (Top::KP <= 256 ? 4 : 2);
+    const uint64_t n_tiles = (t->rows + 63) / 64;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * bpc, (n_tiles + 3) / 4);
+    blocks = std::max(blocks, 1u);
+    const uint32_t lists = blocks * 4;
+    ensure((void**)&t->d_cand, &t->cand_keys, (size_t)lists * kp, sizeof(uint64_t));
+    launch_scan<Top>(t, d_q, kp, lo, t->d_cand, blocks, s);
+    // tree: <= 64 lists per block, then one block
+    if (lists <= 64) {
+        launch_merge<Top>(t->d_cand, lists, kp, lists, keys_out, 1, 0, 0, s);
+    } else {
+        const uint32_t lpb = 32, mid = (lists + lpb - 1) / lpb;
+        ensure((void**)&t->d_tmp, &t->tmp_keys, (size_t)mid * kp, sizeof(uint64_t));
+        launch_merge<Top>(t->d_cand, lists, kp, lpb, t->d_tmp, 1, 0, 0, s);
+        launch_merge<Top>(t->d_tmp, mid, kp, mid, keys_out, 1, 0, 0, s);
+    }
+}
+
+void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
+    if (t->rows == 0) {  // nothing stored: k "none" entries
+        hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s,
+                           (const uint64_t*)nullptr, k, t->base, d_idx, d_dist, (size_t)0, (size_t)0);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    const uint32_t passes = (k + 1023) / 1024;
+    ensure((void**)&t->d_keys, &t->keys_cap, (size_t)passes * 1024, sizeof(uint64_t));
+    for (uint32_t p = 0; p < passes; ++p) {
+        const uint32_t kp = std::min(1024u, k - p * 1024);
+        uint64_t* out = t->d_keys + (size_t)p * 1024;
+        const uint64_t* lo = p ? out - 1 : nullptr;  // last key of the previous pass
+        if (kp <= 64) one_pass<WaveTopReg>(t, d_q, kp, lo, out, s);
+        else if (kp <= 256) one_pass<WaveTopLds<256>>(t, d_q, kp, lo, out, s);
+        else one_pass<WaveTopLds<1024>>(t, d_q, kp, lo, out, s);
+    }
+    hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, t->base,
+                       d_idx, d_dist, (size_t)0, (size_t)0);
+    HIP_CHECK(hipGetLastError());
+}
+
+template <int NQ>
+void launch_batched(mi_knn* t, const float* d_q, uint32_t k, uint64_t* cand, uint32_t blocks, hipStream_t s) {
+    switch (t->dim / 64) {
+        case 12:
+            hipLaunchKernelGGL((knn_scan_batched_kernel<12, NQ>), dim3(blocks), dim3(256), 0, s, t->table, t->rows,
+                               d_q, k, cand);
+            break;
+        default: fail(MI_ERR_UNSUPPORTED, "batched search is built for dim 768 (got %u)", t->dim);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// nq in {2,4,8} queries, k <= 64, one table pass
+void search_batched(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx, float* d_dist,
+                    hipStream_t s) {
+    const uint64_t n_tiles = (t->rows + 63) / 64;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 2, (n_tiles + 3) / 4);
+    blocks = std::max(blocks, 1u);
+    const uint32_t lists = blocks * 4;
+    ensure((void**)&t->d_cand, &t->cand_keys, (size_t)nq * lists * k, sizeof(uint64_t));
+    ensure((void**)&t->d_keys, &t->keys_cap, (size_t)std::max<uint32_t>(1024, nq * k), sizeof(uint64_t));
+    if (nq == 2) launch_batched<2>(t, d_q, k, t->d_cand, blocks, s);
+    else if (nq == 4) launch_batched<4>(t, d_q, k, t->d_cand, blocks, s);
+    else launch_batched<8>(t, d_q, k, t->d_cand, blocks, s);
+    const size_t cstride = (size_t)lists * k;
+    if (lists <= 64) {
+        launch_merge<WaveTopReg>(t->d_cand, lists, k, lists, t->d_keys, nq, cstride, k, s);
+    } else {
+        const uint32_t lpb = 32, mid = (lists + lpb - 1) / lpb;
+        ensure((void**)&t->d_tmp, &t->tmp_keys, (size_t)nq * mid * k, sizeof(uint64_t));
+        launch_merge<WaveTopReg>(t->d_cand, lists, k, lpb, t->d_tmp, nq, cstride, (size_t)mid * k, s);
+        launch_merge<WaveTopReg>(t->d_tmp, mid, k, mid, t->d_keys, nq, (size_t)mid * k, k, s);
+    }
+    hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, nq), dim3(256), 0, s, t->d_keys, k, t->base,
+                       d_idx, d_dist, (size_t)k, (size_t)k);
+    HIP_CHECK(hipGetLastError());
+}
+
+void check_search_args(const mi_knn* t, const void* q, uint32_t nq, uint32_t k, const void* idx, const void* dist) {
+    if (!t) fail(MI_ERR_INVALID, "null table handle");
+    if (nq && (!q || !idx || !dist)) fail(MI_ERR_INVALID, "null query/result pointer");
+    if (k == 0) fail(MI_ERR_INVALID, "k must be >= 1");
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_knn_create(uint32_t dim, int device, mi_knn** out) {
+    return guarded([&] {
+        if (!out) fail(MI_ERR_INVALID, "out is null");
+        *out = nullptr;
+        if (dim == 0 || dim % 64 != 0) fail(MI_ERR_UNSUPPORTED, "dim must be a positive multiple of 64 (got %u)", dim);
+        DeviceGuard g(device);
+        auto t = new mi_knn();
+        t->device = device; t->dim = dim;
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        t->n_cu = prop.multiProcessorCount;
+        HIP_CHECK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipMalloc((void**)&t->d_q, (size_t)16 * dim * sizeof(float)));
+        *out = t;
+    });
+}
+
+void mi_knn_free(mi_knn* t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
+    for (void* p : {(void*)t->table, (void*)t->d_q, (void*)t->d_cand, (void*)t->d_tmp, (void*)t->d_keys,
+                    (void*)t->d_idx, (void*)t->d_dist})
+        if (p) (void)hipFree(p);
+    delete t;
+}
+
+int mi_knn_set_base(mi_knn* t, uint64_t base) {
+    return guarded([&] {
+        if (!t) fail(MI_ERR_INVALID, "null table handle");
+        std::lock_guard<std::mutex> l(t->mu);
+        t->base = base;
+    });
+}
+
+int mi_knn_reserve(mi_knn* t, uint64_t rows) {
+    return guarded([&] {
+        if (!t) fail(MI_ERR_INVALID, "null table handle");
+        std::lock_guard<std::mutex> l(t->mu);
+        DeviceGuard g(t->device);
+        grow(t, rows);
+    });
+}
+
+int mi_knn_size(const mi_knn* t, uint64_t* rows) {
+    return guarded([&] {
+        if (!t || !rows) fail(MI_ERR_INVALID, "null argument");
+        *rows = t->rows;
+    });
+}
+
+int mi_knn_append(mi_knn* t, const float* rows, uint64_t n) {
+    return guarded([&] {
+        if (!t) fail(MI_ERR_INVALID, "null table handle");
+        if (n == 0) return;
+        if (!rows) fail(MI_ERR_INVALID, "rows is null");
+        std::lock_guard<std::mutex> l(t->mu);
+        DeviceGuard g(t->device);
+        grow(t, t->rows + n);
+        HIP_CHECK(hipMemcpyAsync(t->table + t->rows * t->dim, rows, n * t->dim * sizeof(float), hipMemcpyHostToDevice,
+                                 t->stream));
+        HIP_CHECK(hipStreamSynchronize(t->stream));
+        t->rows += n;
+    });
+}
+
+int mi_knn_append_device(mi_knn* t, const float* d_rows, uint64_t n, void* stream) {
+    return guarded([&] {
+        if (!t) fail(MI_ERR_INVALID, "null table handle");
+        if (n == 0) return;
+        if (!d_rows) fail(MI_ERR_INVALID, "d_rows is null");
+        std::lock_guard<std::mutex> l(t->mu);
+        DeviceGuard g(t->device);
+        hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+        if (t->rows + n > t->cap) {  // growing reallocates: make the caller's stream wait for it
+            HIP_CHECK(hipStreamSynchronize(s));
+            grow(t, t->rows + n);
+        }
+        HIP_CHECK(hipMemcpyAsync(t->table + t->rows * t->dim, d_rows, n * t->dim * sizeof(float),
+                                 hipMemcpyDeviceToDevice, s));
+        t->rows += n;
+    });
+}
+
+int mi_knn_append_synthetic(mi_knn* t, uint64_t seed, uint64_t first_row, uint64_t n) {
+    return guarded([&] {
+        if (!t) fail(MI_ERR_INVALID, "null table handle");
+        if (n == 0) return;
+        std::lock_guard<std::mutex> l(t->mu);
+        DeviceGuard g(t->device);
+        grow(t, t->rows + n);
+        const uint64_t key = [&] {  // synth.py: mix64(seed + GOLDEN)
+            uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        }();
+        const float scale = (float)(1.0 / std::sqrt(1431655765.0));
+        hipLaunchKernelGGL(gen_f32_kernel, dim3(t->n_cu * 8), dim3(256), 0, t->stream, t->table + t->rows * t->dim,
+                           key, first_row * t->dim, n * t->dim, scale);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(t->stream));
+        t->rows += n;
+    });
+}
+
+int mi_knn_get_rows(mi_knn* t, uint64_t first, uint64_t n, float* out) {
+    return guarded([&] {
+        if (!t) fail(MI_ERR_INVALID, "null table handle");
+        if (n == 0) return;
+        if (!out) fail(MI_ERR_INVALID, "out is null");
+        std::lock_guard<std::mutex> l(t->mu);
+        if (first + n > t->rows) fail(MI_ERR_INVALID, "rows [%llu,%llu) out of range (size %llu)",
+                                      (unsigned long long)first, (unsigned long long)(first + n),
+                                      (unsigned long long)t->rows);
+        DeviceGuard g(t->device);
+        HIP_CHECK(hipMemcpyAsync(out, t->table + first * t->dim, n * t->dim * sizeof(float), hipMemcpyDeviceToHost,
+                                 t->stream));
+        HIP_CHECK(hipStreamSynchronize(t->stream));
+    });
+}
+
+int mi_knn_search_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx, float* d_dist,
+                         void* stream) {
+    return guarded([&] {
+        check_search_args(t, d_q, nq, k, d_idx, d_dist);
+        std::lock_guard<std::mutex> l(t->mu);
+        DeviceGuard g(t->device);
+        hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+        for (uint32_t u = 0; u < nq; ++u)
+            search_one(t, d_q + (size_t)u * t->dim, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
+    });
+}
+
+int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx,
+                                 float* d_dist, void* stream) {
+    return guarded([&] {
+        check_search_args(t, d_q, nq, k, d_idx, d_dist);
+        if (nq > 16) fail(MI_ERR_UNSUPPORTED, "batched search takes at most 16 queries (got %u)", nq);
+        std::lock_guard<std::mutex> l(t->mu);
+        DeviceGuard g(t->device);
+        hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+        uint32_t u = 0;
+        while (u < nq) {
+            const uint32_t left = nq - u;
+            const uint32_t b = (k <= 64 && t->rows && t->dim == 768) ? (left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1) : 1;
+            if (b == 1) search_one(t, d_q + (size_t)u * t->dim, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
+            else search_batched(t, d_q + (size_t)u * t->dim, b, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
+            u += b;
+        }
+    });
+}
+
+int mi_knn_search(mi_knn* t, const float* q, uint32_t nq, uint32_t k, uint64_t* idx, float* dist) {
+    return guarded([&] {
+        check_search_args(t, q, nq, k, idx, dist);
+        if (nq == 0) return;
+        std::lock_guard<std::mutex> l(t->mu);
+        DeviceGuard g(t->device);
+        ensure((void**)&t->d_idx, &t->idx_cap, k, sizeof(uint64_t));
+        ensure((void**)&t->d_dist, &t->dist_cap, k, sizeof(float));
+        for (uint32_t u = 0; u < nq; ++u) {
+            HIP_CHECK(hipMemcpyAsync(t->d_q, q + (size_t)u * t->dim, t->dim * sizeof(float), hipMemcpyHostToDevice,
+                                     t->stream));
+            search_one(t, t->d_q, k, t->d_idx, t->d_dist, t->stream);
+            HIP_CHECK(hipMemcpyAsync(idx + (size_t)u * k, t->d_idx, k * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                     t->stream));
+            HIP_CHECK(hipMemcpyAsync(dist + (size_t)u * k, t->d_dist, k * sizeof(float), hipMemcpyDeviceToHost,
+                                     t->stream));
+            HIP_CHECK(hipStreamSynchronize(t->stream));
+        }
+    });
+}
+
+}  // extern "C"

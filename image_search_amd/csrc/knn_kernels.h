@@ -1,0 +1,436 @@
+// knn_kernels.h — device code of the cosine K-nearest scan (Seam B).
+//
+// Replaces the SurrealQL statement `embedding <|K|> $reference` over an
+// MTREE ... DIST COSINE TYPE F32 index (server/src/search.rs:70-86,
+// server/src/clip.rs:140-143).  Bound: HBM — one pass reads N*dim*4 bytes.
+//
+// Layout in HBM: table[N][dim] f32 row-major (dim % 64 == 0), exactly the
+// reference's stored `embedding: Vec<f32>` rows (server/src/search.rs:13-18).
+//
+// Scan geometry (wave64): a wave owns a tile of 64 consecutive rows (192 KiB at
+// dim 768).  It walks the tile in 16 steps; in step `it` the 16-lane group g
+// (= lane >> 4) streams row 16g+it: lane i of the group loads the 16 bytes at
+// float offset 64t+4i of every 256-byte chunk t, so each wave-instruction is
+// four fully used 256-byte segments.  Per lane four independent fmaf chains
+// (one per float of the f32x4) run over t; they are then summed by the
+// pairwise xor-butterfly (offsets 1,2 in-lane, 4,8,16,32 across the 16 lanes by
+// DPP) that oracle/oracle.c:orc_dot2 restates — same operands, same order,
+// same bits.  After the 16 steps lane L holds (q.x, x.x) of row 64*tile+L and
+// evaluates  dist = 1 - dot / (sqrt(qq) * sqrt(xx))  once per 64 rows.
+//
+// Selection: every row becomes a 64-bit key  (monotone_u32(dist) << 32) | row,
+// unique per row, so "k smallest keys" IS "(distance asc, id asc), NaN last".
+// Each wave keeps its k best keys and a threshold (its current k-th key); a
+// tile whose 64 keys all exceed the threshold costs one compare + ballot.
+//   KP = 64        (k <= 64): the list lives one key per lane, merged by an
+//                  in-register bitonic network over DPP/bpermute.
+//   KP = 256, 1024 (k <= KP): per-wave LDS list + pending buffer, bitonic
+//                  sort by the wave when the buffer fills.
+// The per-wave lists (waves x k keys) go to HBM and are reduced by
+// knn_merge_kernel in one or two tree levels; knn_finalize_kernel turns keys
+// back into (uint64 id, f32 distance).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint64_t KEY_MAX = 0xFFFFFFFFFFFFFFFFull;
+
+// ---- DPP helpers (16-lane rows) -------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// After the xor-1 and xor-2 steps the four lanes of a quad agree, so the half-mirror
+// (lane -> 7-lane) delivers the other quad's sum = the xor-4 partner's; likewise the
+// row mirror (lane -> 15-lane) is the xor-8 partner once the 8-lane halves agree.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]  : xor 1
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]  : xor 2
+    v += dpp_mov<0x141>(v);  // row_half_mirror      : xor 4
+    v += dpp_mov<0x140>(v);  // row_mirror           : xor 8
+    return v;
+}
+
+// ---- keys -----------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dist_to_u32(float d) {
+    uint32_t b = __float_as_uint(d);
+    if (d != d) return 0xFFFFFFFFu;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float u32_to_dist(uint32_t k) {
+    if (k == 0xFFFFFFFFu) return __uint_as_float(0x7FC00000u);
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+__device__ __forceinline__ uint64_t make_key(float d, uint32_t row) {
+    return ((uint64_t)dist_to_u32(d) << 32) | row;
+}
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
+    uint32_t lo = __shfl((uint32_t)v, src, 64), hi = __shfl((uint32_t)(v >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
+    uint32_t lo = __shfl_xor((uint32_t)v, m, 64), hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a < b ? b : a; }
+
+// ---- per-wave top-k, register form (one key per lane) -----------------------------
+struct WaveTopReg {
+    static constexpr int KP = 64;
+    static constexpr int LDS_KEYS = 0;
+    uint64_t best, thr;
+    uint32_t k;
+    int lane;
+
+    __device__ void init(uint64_t*, uint32_t k_, int lane_) {
+        best = KEY_MAX; thr = KEY_MAX; k = k_; lane = lane_;
+    }
+    __device__ static uint64_t sort_asc(uint64_t v, int lane) {
+#pragma unroll
+        for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                const uint64_t o = shfl_xor64(v, j);
+                const bool up = (lane & kk) == 0, lower = (lane & j) == 0;
+                v = (lower == up) ? umin64(v, o) : umax64(v, o);
+            }
+        }
+        return v;
+    }
+    __device__ static uint64_t merge_bitonic(uint64_t v, int lane) {
+#pragma unroll
+        for (int j = 32; j > 0; j >>= 1) {
+            const uint64_t o = shfl_xor64(v, j);
+            v = ((lane & j) == 0) ? umin64(v, o) : umax64(v, o);
+        }
+        return v;
+    }
+    // wave-collective: every lane offers one key (KEY_MAX = nothing)
+    __device__ void offer(uint64_t key) {
+        const bool pass = key < thr;
+        if (__ballot(pass) == 0ull) return;
+        uint64_t c = sort_asc(pass ? key : KEY_MAX, lane);
+        c = shfl64(c, 63 - lane);
+        best = merge_bitonic(umin64(best, c), lane);
+        thr = shfl64(best, (int)k - 1);
+    }
+    __device__ void finish() {}
+    // store the k best keys, ascending
+    __device__ void store(uint64_t* out) const {
+        if ((uint32_t)lane < k) out[lane] = best;
+    }
+    __device__ uint64_t lane_key(int) const { return best; }
+};
+
+// ---- per-wave top-k, LDS form (KP keys + KP pending) ------------------------------
+template <int KP_>
+struct WaveTopLds {
+    static constexpr int KP = KP_;
+    static constexpr int LDS_KEYS = 2 * KP_;
+    uint64_t* buf;  // [0,KP) best ascending, [KP,2KP) pending
+    uint64_t thr;
+    uint32_t k, cnt;
+    int lane;
+
+    __device__ static void wave_sync() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ void init(uint64_t* lds, uint32_t k_, int lane_) {
+        buf = lds; k = k_; lane = lane_; cnt = 0; thr = KEY_MAX;
+        for (int j = lane; j < 2 * KP; j += 64) buf[j] = KEY_MAX;
+        wave_sync();
+    }
+    __device__ void merge() {
+        wave_sync();
+        // ascending bitonic sort of all 2KP keys by this wave
+        for (int kk = 2; kk <= 2 * KP; kk <<= 1) {
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int p = lane; p < KP; p += 64) {
+                    const int a = ((p & ~(j - 1)) << 1) | (p & (j - 1));  // bit j clear
+                    const int b = a | j;
+                    const uint64_t x = buf[a], y = buf[b];
+                    const bool up = (a & kk) == 0;
+                    if ((x > y) == up) { buf[a] = y; buf[b] = x; }
+                }
+                wave_sync();
+            }
+        }
+        thr = buf[k - 1];
+        thr = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(thr >> 32)) << 32) |
+              __builtin_amdgcn_readfirstlane((uint32_t)thr);
+        wave_sync();
+        for (int j = KP + lane; j < 2 * KP; j += 64) buf[j] = KEY_MAX;
+        cnt = 0;
+        wave_sync();
+    }
+    __device__ void offer(uint64_t key) {
+        const bool pass = key < thr;
+        const unsigned long long mask = __ballot(pass);
+        if (mask == 0ull) return;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+        if (pass) buf[KP + cnt + rank] = key;
+        cnt += (uint32_t)__popcll(mask);
+        if (cnt + 64 > (uint32_t)KP) merge();
+    }
+    __device__ void finish() {
+        if (cnt) merge(); else wave_sync();
+    }
+    __device__ void store(uint64_t* out) const {
+        for (uint32_t j = lane; j < k; j += 64) out[j] = buf[j];
+    }
+    __device__ uint64_t lane_key(int j) const { return buf[j]; }
+};
+
+// ---- the scan ---------------------------------------------------------------------
+// One fp32 fmaf per (row element, accumulator); NCH = dim / 64 chunks of 256 bytes.
+template <int NCH>
+struct RowAcc {
+    float d0, d1, d2, d3, s0, s1, s2, s3;
+    __device__ __forceinline__ void zero() { d0 = d1 = d2 = d3 = s0 = s1 = s2 = s3 = 0.0f; }
+    __device__ __forceinline__ void step(const f32x4& q, const f32x4& x) {
+        d0 = __builtin_fmaf(q.x, x.x, d0); d1 = __builtin_fmaf(q.y, x.y, d1);
+        d2 = __builtin_fmaf(q.z, x.z, d2); d3 = __builtin_fmaf(q.w, x.w, d3);
+        s0 = __builtin_fmaf(x.x, x.x, s0); s1 = __builtin_fmaf(x.y, x.y, s1);
+        s2 = __builtin_fmaf(x.z, x.z, s2); s3 = __builtin_fmaf(x.w, x.w, s3);
+    }
+    __device__ __forceinline__ float dot() const { return row16_sum((d0 + d1) + (d2 + d3)); }
+    __device__ __forceinline__ float sumsq() const { return row16_sum((s0 + s1) + (s2 + s3)); }
+};
+
+// grid: any number of 256-thread blocks; wave w of the grid takes tiles w, w+W, ...
+// cand: [gridDim.x*4][k] keys out.  lo_ptr (nullable): keys <= *lo_ptr are skipped
+// (used when k > 1024 is served in several passes).
+template <int NCH, class Top>
+__global__ __launch_bounds__(256, 2) void knn_scan_kernel(const float* __restrict__ table, uint64_t n_rows,
+                                                       const float* __restrict__ q, uint32_t k,
+                                                       const uint64_t* __restrict__ lo_ptr,
+                                                       uint64_t* __restrict__ cand) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int DIM = NCH * 64;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const uint32_t wave = blockIdx.x * 4 + wib, n_waves = gridDim.x * 4;
+
+    f32x4 qf[NCH];
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) qf[t] = *reinterpret_cast<const f32x4*>(q + 64 * t + 4 * i);
+    float sq;  // sqrt(q.q), same summation order as a row
+    {
+        RowAcc<NCH> a; a.zero();
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) a.step(qf[t], qf[t]);
+        sq = sqrtf(a.sumsq());
+    }
+    const uint64_t lo = lo_ptr ? *lo_ptr : 0ull;
+    const bool use_lo = lo_ptr != nullptr;
+
+    Top top;
+    top.init(reinterpret_cast<uint64_t*>(smem) + (size_t)wib * Top::LDS_KEYS, k, lane);
+
+    const uint64_t n_tiles = (n_rows + 63) >> 6;
+    // two row buffers: the loads of step it+1 are in flight while step it is summed
+    auto load_row = [&](f32x4 (&x)[NCH], uint64_t r) {
+        r = r < n_rows ? r : n_rows - 1;
+        const f32x4* p = reinterpret_cast<const f32x4*>(table + r * DIM) + i;
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) x[t] = __builtin_nontemporal_load(p + 16 * t);
+    };
+    for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
+        float mydot = 0.0f, myxx = 1.0f;
+        const uint64_t row0 = (tile << 6) + 16 * g;
+        auto reduce_row = [&](const f32x4 (&x)[NCH], int it) {
+            RowAcc<NCH> a; a.zero();
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) a.step(qf[t], x[t]);
+            const float d = a.dot(), s = a.sumsq();
+            if (i == it) { mydot = d; myxx = s; }
+        };
+        f32x4 xa[NCH], xb[NCH];
+        load_row(xa, row0);
+#pragma unroll 1
+        for (int it = 0; it < 16; it += 2) {
+            load_row(xb, row0 + it + 1);
+            reduce_row(xa, it);
+            load_row(xa, row0 + (it + 2 < 16 ? it + 2 : 15));
+            reduce_row(xb, it + 1);
+        }
+        const uint64_t r = (tile << 6) + lane;
+        const float dist = 1.0f - mydot / (sq * sqrtf(myxx));
+        uint64_t key = r < n_rows ? make_key(dist, (uint32_t)r) : KEY_MAX;
+        if (use_lo && key <= lo) key = KEY_MAX;
+        top.offer(key);
+    }
+    top.finish();
+    top.store(cand + (size_t)wave * k);
+}
+
+// Q queries in one pass over the table (throughput variant).  Same per-row
+// arithmetic per query, so results equal Q single-query scans.  q: [NQ][dim].
+template <int NCH, int NQ>
+__global__ __launch_bounds__(256) void knn_scan_batched_kernel(const float* __restrict__ table, uint64_t n_rows,
+                                                               const float* __restrict__ q, uint32_t k,
+                                                               uint64_t* __restrict__ cand /*[NQ][waves][k]*/) {
+    constexpr int DIM = NCH * 64;
+    __shared__ __attribute__((aligned(16))) float qs[NQ * DIM];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const uint32_t wave = blockIdx.x * 4 + wib, n_waves = gridDim.x * 4;
+    for (int j = threadIdx.x; j < NQ * DIM; j += 256) qs[j] = q[j];
+    __syncthreads();
+
+    float sq[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        RowAcc<NCH> a; a.zero();
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&qs[u * DIM + 64 * t + 4 * i]);
+            a.step(v, v);
+        }
+        sq[u] = sqrtf(a.sumsq());
+    }
+    WaveTopReg top[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) top[u].init(nullptr, k, lane);
+
+    const uint64_t n_tiles = (n_rows + 63) >> 6;
+    for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
+        float mydot[NQ], myxx = 1.0f;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) mydot[u] = 0.0f;
+        const uint64_t row0 = (tile << 6) + 16 * g;
+        for (int it = 0; it < 16; ++it) {
+            uint64_t r = row0 + it;
+            r = r < n_rows ? r : n_rows - 1;
+            const f32x4* p = reinterpret_cast<const f32x4*>(table + r * DIM) + i;
+            f32x4 x[NCH];
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) x[t] = __builtin_nontemporal_load(p + 16 * t);
+            float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                s0 = __builtin_fmaf(x[t].x, x[t].x, s0); s1 = __builtin_fmaf(x[t].y, x[t].y, s1);
+                s2 = __builtin_fmaf(x[t].z, x[t].z, s2); s3 = __builtin_fmaf(x[t].w, x[t].w, s3);
+            }
+            const float s = row16_sum((s0 + s1) + (s2 + s3));
+            if (i == it) myxx = s;
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                float d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+                for (int t = 0; t < NCH; ++t) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&qs[u * DIM + 64 * t + 4 * i]);
+                    d0 = __builtin_fmaf(v.x, x[t].x, d0); d1 = __builtin_fmaf(v.y, x[t].y, d1);
+                    d2 = __builtin_fmaf(v.z, x[t].z, d2); d3 = __builtin_fmaf(v.w, x[t].w, d3);
+                }
+                const float d = row16_sum((d0 + d1) + (d2 + d3));
+                if (i == it) mydot[u] = d;
+            }
+        }
+        const uint64_t r = (tile << 6) + lane;
+        const float sx = sqrtf(myxx);
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const float dist = 1.0f - mydot[u] / (sq[u] * sx);
+            top[u].offer(r < n_rows ? make_key(dist, (uint32_t)r) : KEY_MAX);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) top[u].store(cand + ((size_t)u * n_waves + wave) * k);
+}
+
+// ---- tree reduction of candidate lists ----------------------------------------------
+// block b merges lists [b*lpb, min(n_lists,(b+1)*lpb)) of k keys each into one list.
+// `in`/`out` are indexed per query by blockIdx.y (strides in keys).
+template <class Top>
+__global__ __launch_bounds__(256) void knn_merge_kernel(const uint64_t* __restrict__ in, uint32_t n_lists,
+                                                        uint32_t k, uint32_t lpb, uint64_t* __restrict__ out,
+                                                        size_t in_stride, size_t out_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint64_t wave_best[4][64];  // register form hands its lists over through here
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    in += blockIdx.y * in_stride;
+    out += blockIdx.y * out_stride;
+    const uint32_t l0 = blockIdx.x * lpb;
+    const uint32_t l1 = min(n_lists, l0 + lpb);
+    const uint64_t* src = in + (size_t)l0 * k;
+    const uint32_t n_keys = (l1 - l0) * k;
+
+    Top top;
+    uint64_t* my_lds = reinterpret_cast<uint64_t*>(smem) + (size_t)wib * Top::LDS_KEYS;
+    top.init(my_lds, k, lane);
+    for (uint32_t j0 = 0; j0 < n_keys; j0 += 256) {
+        const uint32_t j = j0 + threadIdx.x;
+        top.offer(j < n_keys ? src[j] : KEY_MAX);
+    }
+    top.finish();
+    if (Top::LDS_KEYS == 0) wave_best[wib][lane] = top.lane_key(lane);
+    __syncthreads();
+    if (wib == 0) {
+        for (int w = 1; w < 4; ++w) {
+            if (Top::LDS_KEYS == 0) {
+                top.offer(wave_best[w][lane]);
+            } else {
+                const uint64_t* other = reinterpret_cast<uint64_t*>(smem) + (size_t)w * Top::LDS_KEYS;
+                for (uint32_t j = 0; j < (uint32_t)Top::KP; j += 64) {
+                    const uint32_t idx = j + lane;
+                    top.offer(idx < k ? other[idx] : KEY_MAX);
+                }
+            }
+        }
+        top.finish();
+        top.store(out + (size_t)blockIdx.x * k);
+    }
+}
+
+// keys (ascending, KEY_MAX = none) -> (id, distance); one thread per result slot.
+__global__ void knn_finalize_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint64_t base,
+                                    uint64_t* __restrict__ idx, float* __restrict__ dist,
+                                    size_t key_stride, size_t out_stride) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t key = keys ? keys[blockIdx.y * key_stride + j] : KEY_MAX;
+    uint64_t* oi = idx + blockIdx.y * out_stride;
+    float* od = dist + blockIdx.y * out_stride;
+    if (key == KEY_MAX) {
+        oi[j] = MI_KNN_NO_ID;
+        od[j] = __uint_as_float(0x7F800000u);
+    } else {
+        oi[j] = base + (uint32_t)key;
+        od[j] = u32_to_dist((uint32_t)(key >> 32));
+    }
+}
+
+// ---- seeded corpus generator (image_search_amd/synth.py gen_f32, bit for bit) ---------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float gen1(uint64_t key, uint64_t i, float scale) {
+    const uint64_t h = mix64(i + key);
+    const int s = (int)((h & 0xffff) + ((h >> 16) & 0xffff) + ((h >> 32) & 0xffff) + (h >> 48));
+    return (float)(s - 131070) * scale;
+}
+// out[j] = value(counter first+j), j < n; n % 4 == 0, out 16-byte aligned
+__global__ void gen_f32_kernel(float* __restrict__ out, uint64_t key, uint64_t first, uint64_t n, float scale) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 4;
+    for (uint64_t j = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; j < n; j += stride) {
+        f32x4 v;
+        v.x = gen1(key, first + j, scale); v.y = gen1(key, first + j + 1, scale);
+        v.z = gen1(key, first + j + 2, scale); v.w = gen1(key, first + j + 3, scale);
+        *reinterpret_cast<f32x4*>(out + j) = v;
+    }
+}
+
+}  // namespace mi

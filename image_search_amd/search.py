@@ -1,0 +1,162 @@
+"""Host-side mirror of the reference's query/refine loop and kNN statement
+(/root/reference/server/src/search.rs) on top of the C ABI.
+
+`average_slices` and `refine_query` keep the reference's names, argument meaning
+and error behaviour (search.rs:127-150, :60-67); `EmbeddingTable` stands where the
+SurrealDB table `image` + index `mt_pts` stood (clip.rs:135-143) and its
+`knn()` is the `embedding <|K|> $reference` statement (search.rs:70-86).
+`ShardedTable` is the multi-GPU form: one process per GPU, rows split
+contiguously, per-shard top-k all-gathered (RCCL over xGMI via torch.distributed)
+and merged identically on every rank.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Sequence
+
+import numpy as np
+
+from ._lib import c_f, c_vp, check, lib
+
+K_REFERENCE = 1000  # `<|1000|>` in server/src/search.rs:76
+NO_ID = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptrs(vecs):
+    arr = (c_f * len(vecs))()
+    for i, v in enumerate(vecs):
+        arr[i] = v.ctypes.data_as(c_f)
+    return arr
+
+
+def average_slices(vectors: Sequence[np.ndarray]) -> np.ndarray:
+    """fn average_slices(vectors: &Vec<&Vec<f32>>) -> Vec<f32>  (search.rs:127-150).
+    Panics in the reference on empty input / ragged lengths; raises here."""
+    if len(vectors) == 0:
+        raise AssertionError("Input must not be empty")
+    vecs = [_f32(v).reshape(-1) for v in vectors]
+    n = vecs[0].size
+    if any(v.size != n for v in vecs):
+        raise AssertionError("All vectors must have the same length")
+    out = np.empty(n, np.float32)
+    check(lib().mi_average_slices(_ptrs(vecs), len(vecs), n, out.ctypes.data_as(c_f)))
+    return out
+
+
+def refine_query(text_embedding: np.ndarray, selected: Sequence[np.ndarray]) -> np.ndarray:
+    """search.rs:28,:60-67 — no marked image found: the text vector itself; else
+    average_slices([average_slices(selected), text])."""
+    text = _f32(text_embedding).reshape(-1)
+    sel = [_f32(v).reshape(-1) for v in selected]
+    if any(v.size != text.size for v in sel):
+        raise AssertionError("All vectors must have the same length")
+    out = np.empty_like(text)
+    check(lib().mi_refine(text.ctypes.data_as(c_f), _ptrs(sel), len(sel), text.size, out.ctypes.data_as(c_f)))
+    return out
+
+
+class EmbeddingTable:
+    """One row-shard of `image.embedding` resident in HBM (mi_knn)."""
+
+    def __init__(self, dim: int = 768, device: int = 0, base: int = 0):
+        self._h = c_vp()
+        self.dim, self.device = dim, device
+        check(lib().mi_knn_create(dim, device, ctypes.byref(self._h)))
+        if base:
+            self.set_base(base)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mi_knn_free(self._h)
+            self._h = c_vp()
+
+    __del__ = close
+
+    def __len__(self) -> int:
+        n = ctypes.c_uint64()
+        check(lib().mi_knn_size(self._h, ctypes.byref(n)))
+        return n.value
+
+    def set_base(self, base: int):
+        check(lib().mi_knn_set_base(self._h, base))
+
+    def reserve(self, rows: int):
+        check(lib().mi_knn_reserve(self._h, rows))
+
+    def insert(self, embeddings: np.ndarray):
+        """db.insert("image").content(rows) (clip.rs:125-137): ids are insertion ordinals."""
+        e = _f32(embeddings).reshape(-1, self.dim)
+        check(lib().mi_knn_append(self._h, e.ctypes.data, e.shape[0]))
+
+    def insert_device(self, d_ptr: int, n: int, stream: int = 0):
+        check(lib().mi_knn_append_device(self._h, d_ptr, n, stream))
+
+    def insert_synthetic(self, seed: int, first_row: int, n: int):
+        check(lib().mi_knn_append_synthetic(self._h, seed, first_row, n))
+
+    def rows(self, first: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.dim), np.float32)
+        check(lib().mi_knn_get_rows(self._h, first, n, out.ctypes.data))
+        return out
+
+    def knn(self, reference: np.ndarray, k: int = K_REFERENCE):
+        """`WHERE embedding <|k|> $reference` (search.rs:70-77): (ids, cosine distances),
+        ascending distance then id.  reference: [dim] or [nq,dim]."""
+        q = _f32(reference)
+        single = q.ndim == 1
+        q = q.reshape(-1, self.dim)
+        idx = np.empty((q.shape[0], k), np.uint64)
+        dist = np.empty((q.shape[0], k), np.float32)
+        check(lib().mi_knn_search(self._h, q.ctypes.data, q.shape[0], k, idx.ctypes.data, dist.ctypes.data))
+        return (idx[0], dist[0]) if single else (idx, dist)
+
+    def knn_device(self, d_q: int, nq: int, k: int, d_idx: int, d_dist: int, stream: int = 0, batched: bool = False):
+        fn = lib().mi_knn_search_batched_device if batched else lib().mi_knn_search_device
+        check(fn(self._h, d_q, nq, k, d_idx, d_dist, stream))
+
+
+def merge_candidates(idx_lists: np.ndarray, dist_lists: np.ndarray, k: int):
+    """Global top-k of `lists` per-shard candidate lists (same ordering rule)."""
+    i = np.ascontiguousarray(idx_lists, np.uint64).reshape(-1)
+    d = np.ascontiguousarray(dist_lists, np.float32).reshape(-1)
+    assert i.size == d.size and i.size % k == 0
+    idx = np.empty(k, np.uint64)
+    dist = np.empty(k, np.float32)
+    check(lib().mi_knn_merge(i.ctypes.data, d.ctypes.data, i.size // k, k, idx.ctypes.data, dist.ctypes.data))
+    return idx, dist
+
+
+def shard_bounds(n_rows: int, world: int, rank: int):
+    """Contiguous row split: rank r owns [r*N/W, (r+1)*N/W)."""
+    return (n_rows * rank) // world, (n_rows * (rank + 1)) // world
+
+
+def gather_and_merge(local_idx: np.ndarray, local_dist: np.ndarray, k: int, group=None):
+    """The one exchange step of the sharded search: all-gather every rank's k
+    candidates (12*k bytes per rank and query) and merge them identically on
+    every rank.  Works on any torch.distributed backend (nccl == RCCL on ROCm,
+    gloo on CPU); tensors live where the backend needs them."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    nq = local_idx.shape[0] if local_idx.ndim == 2 else 1
+    li = torch.from_numpy(np.ascontiguousarray(local_idx, np.uint64).view(np.int64).reshape(nq, k))
+    ld = torch.from_numpy(np.ascontiguousarray(local_dist, np.float32).reshape(nq, k))
+    if dist.get_backend(group) == "nccl":
+        li, ld = li.cuda(), ld.cuda()
+    gi = torch.empty((world,) + tuple(li.shape), dtype=li.dtype, device=li.device)
+    gd = torch.empty((world,) + tuple(ld.shape), dtype=ld.dtype, device=ld.device)
+    dist.all_gather_into_tensor(gi, li, group=group)
+    dist.all_gather_into_tensor(gd, ld, group=group)
+    gi = gi.cpu().numpy().view(np.uint64)  # [world, nq, k]
+    gd = gd.cpu().numpy()
+    out_i = np.empty((nq, k), np.uint64)
+    out_d = np.empty((nq, k), np.float32)
+    for u in range(nq):
+        out_i[u], out_d[u] = merge_candidates(gi[:, u, :], gd[:, u, :], k)
+    return out_i, out_d

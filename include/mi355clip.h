@@ -1,0 +1,160 @@
+/*
+ * mi355clip.h — C ABI of libmi355clip.so: the MI355X (gfx950) replacement for the
+ * one compute hot path of olFi95/image_search:
+ *   Seam A  CLIP ViT-L/14 image tower   [n,3,224,224] f32 -> [n,768] f32
+ *   Seam B  cosine K-nearest over the stored [N,768] f32 embedding table
+ *   + the 24-line query refinement (average_slices).
+ * The reference has no FFI of its own; each entry point below cites the reference
+ * call site (file:line under /root/reference) whose semantics it pins.  The Rust
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; opaque handles; caller owns every buffer.
+ *   - every function returns MI_OK (0) or a negative MI_ERR_*; nothing throws,
+ *     aborts or panics across the ABI (the reference panics/aborts on errors,
+ *     server/Cargo.toml:9 — a drop-in must not).  mi_last_error() gives the
+ *     thread-local message of the last failure on the calling thread.
+ *   - a handle serialises internally (one mutex per handle, the reference's
+ *     model: server/src/main.rs:33-34); distinct handles are independent.
+ *   - "host" pointers are ordinary memory; "_device" entry points take HIP
+ *     device pointers on the handle's device and a hipStream_t passed as void*
+ *     (NULL = the handle's own stream) and do not synchronise the stream.
+ *   - there is NO CPU fallback: without a usable gfx950 device, creation fails
+ *     with MI_ERR_NO_DEVICE.
+ */
+#ifndef MI355CLIP_H
+#define MI355CLIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_ERR_INVALID (-1)     /* bad argument (null pointer, zero dim, ...) */
+#define MI_ERR_IO (-2)          /* weights file missing / unreadable / malformed */
+#define MI_ERR_HIP (-3)         /* a HIP runtime call failed */
+#define MI_ERR_NO_DEVICE (-4)   /* no gfx950 device with that ordinal */
+#define MI_ERR_UNSUPPORTED (-5) /* shape outside what the kernels are built for */
+#define MI_ERR_OOM (-6)
+
+#define MI_PRECISION_F32 0  /* fp32 in / fp32 accumulate: the parity path (<= 1e-4 rel) */
+#define MI_PRECISION_BF16 1 /* bf16 MFMA operands, fp32 accumulate + fp32 residual stream */
+
+#define MI_KNN_NO_ID UINT64_MAX /* id written for missing results (fewer than k rows) */
+
+typedef struct mi_clip mi_clip; /* a loaded vision tower on one GPU */
+typedef struct mi_knn mi_knn;   /* one row-shard of the embedding table on one GPU */
+
+const char* mi_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int mi_abi_version(void);
+/* number of visible HIP devices (0 when there is none; never fails hard). */
+int mi_device_count(void);
+
+/* ---------------------------------------------------------------- Seam A: ViT */
+
+/* Replaces clip::clip_vit_large_patch14::Model::from_file(path, &device)
+ * (server/src/clip.rs:46-48; weights produced by clip/build.rs:75-83).
+ * `weights_path` is a Hugging Face safetensors file holding the
+ * CLIPVisionModelWithProjection tensors (vision_model.* + visual_projection.weight,
+ * F32/F16/BF16); dimensions are read from the tensor shapes, so any CLIP ViT
+ * geometry with head_dim 64 loads (ViT-L/14: 24 x 1024, 16 heads, 257 tokens).
+ * The handle is meant to stay resident across scans (the reference reloads
+ * 1.16 GB on every scan). */
+int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** out);
+void mi_clip_free(mi_clip* m);
+
+/* geometry of a loaded model: out[0..7] = image, patch, tokens, hidden, layers,
+ * heads, ff, proj */
+int mi_clip_info(const mi_clip* m, uint32_t out[8]);
+
+/* Replaces `model.forward(Tensor::from_data(TensorData::new(buf,[n,3,224,224])))`
+ * + `output.to_data()` (server/src/clip.rs:112-124).  Host pointers.
+ * nchw: [n,3,H,W] contiguous f32 (H = W = 224 for ViT-L/14), as
+ * image_prepare_resnet lays it out (server/src/clip.rs:153-175);
+ * out: [n,proj] contiguous f32 (proj = 768), NOT L2-normalised.
+ * n = 0 is a successful no-op (the reference calls forward on an empty chunk,
+ * server/src/clip.rs:112-118).  Any n: tiled internally. */
+int mi_clip_embed(mi_clip* m, const float* nchw, size_t n, float* out);
+
+/* Same computation on device-resident buffers (rows (a3) of SURVEY.md §8:
+ * removes the two host copies and the blocking readback of
+ * server/src/clip.rs:107-124).  Asynchronous on `stream`. */
+int mi_clip_embed_device(mi_clip* m, const float* d_nchw, size_t n, float* d_out, void* stream);
+
+/* image_prepare_resnet's arithmetic (server/src/clip.rs:158-172) fused in front
+ * of the tower: rgb8 = [n,H,W,3] interleaved u8 already at model resolution
+ * (what `resize_exact(..).to_rgb8().as_raw()` returns), host pointers. */
+int mi_clip_embed_rgb8(mi_clip* m, const uint8_t* rgb8, size_t n, float* out);
+
+/* host-only restatement of the same arithmetic for callers that keep the
+ * reference's two-step flow: rgb8 [n,H,W,3] -> chw f32 [n,3,H,W]. */
+int mi_preprocess_rgb8(const uint8_t* rgb8, size_t n, uint32_t height, uint32_t width, float* chw);
+
+/* ---------------------------------------------------------------- Seam B: kNN */
+
+/* One shard of table `image{embedding}` (server/src/search.rs:13-18; index DDL
+ * server/src/clip.rs:140-143: DIMENSION 768, DIST COSINE, TYPE F32) resident in
+ * HBM as row-major f32.  dim must be a multiple of 64.  Row ids are
+ * base + insertion ordinal (uint64); base defaults to 0 and is the shard's
+ * first global row when the table is row-sharded over several GPUs. */
+int mi_knn_create(uint32_t dim, int device, mi_knn** out);
+void mi_knn_free(mi_knn* t);
+int mi_knn_set_base(mi_knn* t, uint64_t base);
+int mi_knn_reserve(mi_knn* t, uint64_t rows); /* capacity hint; keeps contents */
+int mi_knn_size(const mi_knn* t, uint64_t* rows);
+
+/* Replaces db.insert("image").content(rows) (server/src/clip.rs:125-137): append n
+ * rows of dim f32 (host pointers). */
+int mi_knn_append(mi_knn* t, const float* rows, uint64_t n);
+/* append rows already on the device (e.g. straight from mi_clip_embed_device) */
+int mi_knn_append_device(mi_knn* t, const float* d_rows, uint64_t n, void* stream);
+/* append n synthetic rows generated on the device: global rows
+ * [first_row, first_row+n) of the seeded corpus of image_search_amd/synth.py */
+int mi_knn_append_synthetic(mi_knn* t, uint64_t seed, uint64_t first_row, uint64_t n);
+/* copy rows [first, first+n) back to the host (tests, refine's row fetch:
+ * server/src/search.rs:43-58) */
+int mi_knn_get_rows(mi_knn* t, uint64_t first, uint64_t n, float* out);
+
+/* Replaces `SELECT id, image_path, vector::distance::knn() FROM image WHERE
+ * embedding <|K|> $reference` (server/src/search.rs:70-86; K = 1000 there).
+ * For each of nq queries (q: [nq,dim] host f32): the k rows of this shard with the
+ * smallest cosine distance 1 - q.x/(|q||x|), sorted by (distance asc, id asc);
+ * NaN distances (zero-norm row or query) sort last.  idx: [nq,k] uint64,
+ * dist: [nq,k] f32.  Fewer than k rows: the tail is MI_KNN_NO_ID / +inf.
+ * Each query is one pass over the table (the reference serves one query per
+ * request, server/src/search.rs:20-102). */
+int mi_knn_search(mi_knn* t, const float* q, uint32_t nq, uint32_t k, uint64_t* idx, float* dist);
+/* Same, queries and results on the device, asynchronous on `stream`.
+ * d_idx [nq,k] uint64 and d_dist [nq,k] f32 are what each rank feeds to the
+ * all-gather when the table is sharded. */
+int mi_knn_search_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx,
+                         float* d_dist, void* stream);
+/* Throughput variant: ONE pass over the table serves all nq queries (nq <= 16);
+ * results identical to nq calls of mi_knn_search_device with nq = 1. */
+int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx,
+                                 float* d_dist, void* stream);
+
+/* Deterministic merge of `lists` candidate lists of k (id, dist) entries each —
+ * what every rank holds after the all-gather of per-shard results — into the
+ * global top-k under the same ordering.  Host-only. */
+int mi_knn_merge(const uint64_t* idx_in, const float* dist_in, uint32_t lists, uint32_t k,
+                 uint64_t* idx, float* dist);
+
+/* ------------------------------------------------------------ query refinement */
+
+/* fn average_slices(vectors: &Vec<&Vec<f32>>) -> Vec<f32> (server/src/search.rs:127-150):
+ * zero-init, add in input order, divide by (m as f32).  m = 0 -> MI_ERR_INVALID
+ * (the reference asserts "Input must not be empty"). */
+int mi_average_slices(const float* const* vectors, size_t m, size_t len, float* out);
+/* the refine step of web_search_text (server/src/search.rs:28, :60-67):
+ * m = 0 -> out = text; else out = average_slices([average_slices(selected), text]). */
+int mi_refine(const float* text, const float* const* selected, size_t m, size_t len, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355CLIP_H */
