@@ -43,6 +43,13 @@ SYMBOLS = {
     "mi_knn_merge": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     "mi_average_slices": (ctypes.c_int, [ctypes.POINTER(c_f), ctypes.c_size_t, ctypes.c_size_t, c_f]),
     "mi_refine": (ctypes.c_int, [c_f, ctypes.POINTER(c_f), ctypes.c_size_t, ctypes.c_size_t, c_f]),
+    # include/mi355clip_ops.h (per-op test hooks)
+    "mi_op_linear": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_vp,
+                                    ctypes.c_size_t, ctypes.c_int, ctypes.c_int]),
+    "mi_op_attention": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_size_t, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int]),
+    "mi_op_layernorm": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t,
+                                       ctypes.c_int, ctypes.c_float]),
 }
 
 MI_OK = 0

@@ -1,0 +1,88 @@
+"""Host-side mirror of the reference's ViT seam on top of the C ABI.
+
+`clip_vit_large_patch14.Model.from_file(path, device)` and `.forward(tensor)` keep
+the names and argument meaning of the generated Burn module the reference calls
+(/root/reference/clip/src/lib.rs:2-7, call sites server/src/clip.rs:46-48, :118);
+`image_prepare_resnet` is server/src/clip.rs:153-175 minus the resize (the `image`
+crate's CatmullRom `resize_exact` is upstream of this path: SURVEY.md §8f rank 2).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from ._lib import c_vp, check, lib
+
+PRECISION_F32 = 0   # parity path (<= 1e-4 relative vs the fp32 CPU oracle)
+PRECISION_BF16 = 1  # throughput path (bf16 MFMA operands, fp32 accumulate/residual)
+
+EXTENSIONS = ("jpg", "jpeg", "png", "gif", "bmp", "webp", "tiff")
+
+
+def is_image_path(path: str) -> bool:
+    """The extension allow-list of the ingest walk (server/src/clip.rs:60-66;
+    the reference's own unit test `test_matches`, clip.rs:181-233)."""
+    name = path.replace("\\", "/").rsplit("/", 1)[-1]
+    dot = name.rfind(".")
+    if dot <= 0:  # no '.', or a dot-file: Rust's Path::extension() is None
+        return False
+    return name[dot + 1:].lower() in EXTENSIONS
+
+
+def image_prepare_resnet(rgb8_hwc: np.ndarray) -> np.ndarray:
+    """RGB8 HWC (already 224x224) -> CHW f32, ImageNet mean/std (clip.rs:158-172)."""
+    a = np.ascontiguousarray(rgb8_hwc, np.uint8)
+    single = a.ndim == 3
+    a = a.reshape((-1,) + a.shape[-3:])
+    n, h, w, _ = a.shape
+    out = np.empty((n, 3, h, w), np.float32)
+    check(lib().mi_preprocess_rgb8(a.ctypes.data, n, h, w, out.ctypes.data))
+    return out[0] if single else out
+
+
+class Model:
+    """clip::clip_vit_large_patch14::Model<B> on one MI355X."""
+
+    def __init__(self, handle: c_vp):
+        self._h = handle
+        info = (ctypes.c_uint32 * 8)()
+        check(lib().mi_clip_info(self._h, info))
+        (self.image, self.patch, self.tokens, self.hidden, self.layers, self.heads, self.ff, self.proj) = list(info)
+
+    @classmethod
+    def from_file(cls, path: str, device: int = 0, precision: int = PRECISION_F32) -> "Model":
+        h = c_vp()
+        check(lib().mi_clip_load(path.encode(), device, precision, ctypes.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mi_clip_free(self._h)
+            self._h = c_vp()
+
+    __del__ = close
+
+    def forward(self, tensor: np.ndarray) -> np.ndarray:
+        """[n,3,H,W] f32 NCHW -> [n,proj] f32 (clip.rs:112-124); n == 0 allowed."""
+        x = np.ascontiguousarray(tensor, np.float32)
+        if x.ndim != 4 or x.shape[1:] != (3, self.image, self.image):
+            raise ValueError(f"expected [n,3,{self.image},{self.image}], got {x.shape}")
+        out = np.empty((x.shape[0], self.proj), np.float32)
+        check(lib().mi_clip_embed(self._h, x.ctypes.data, x.shape[0], out.ctypes.data))
+        return out
+
+    def forward_rgb8(self, rgb8_hwc: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(rgb8_hwc, np.uint8)
+        if a.ndim != 4 or a.shape[1:] != (self.image, self.image, 3):
+            raise ValueError(f"expected [n,{self.image},{self.image},3] u8, got {a.shape}")
+        out = np.empty((a.shape[0], self.proj), np.float32)
+        check(lib().mi_clip_embed_rgb8(self._h, a.ctypes.data, a.shape[0], out.ctypes.data))
+        return out
+
+    def forward_device(self, d_nchw: int, n: int, d_out: int, stream: int = 0):
+        check(lib().mi_clip_embed_device(self._h, d_nchw, n, d_out, stream))
+
+
+class clip_vit_large_patch14:  # noqa: N801 — the reference's module name
+    Model = Model

@@ -1,11 +1,637 @@
-// vit.hip — Seam A (placeholder while the kernels are brought up).
+// vit.hip — host side of Seam A behind the C ABI (include/mi355clip.h):
+// mi_clip_load  <- clip::clip_vit_large_patch14::Model::from_file (server/src/clip.rs:46-48)
+// mi_clip_embed <- model.forward + to_data                         (server/src/clip.rs:112-124)
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "common.h"
+#include "../../include/mi355clip_ops.h"
+#include "vit_kernels.h"
+
 using namespace mi;
-extern "C" {
-int mi_clip_load(const char*, int, int, mi_clip** out) { return guarded([&] { if (out) *out = nullptr; fail(MI_ERR_UNSUPPORTED, "ViT path not built yet"); }); }
-void mi_clip_free(mi_clip*) {}
-int mi_clip_info(const mi_clip*, uint32_t*) { return guarded([&] { fail(MI_ERR_UNSUPPORTED, "ViT path not built yet"); }); }
-int mi_clip_embed(mi_clip*, const float*, size_t, float*) { return guarded([&] { fail(MI_ERR_UNSUPPORTED, "ViT path not built yet"); }); }
-int mi_clip_embed_device(mi_clip*, const float*, size_t, float*, void*) { return guarded([&] { fail(MI_ERR_UNSUPPORTED, "ViT path not built yet"); }); }
-int mi_clip_embed_rgb8(mi_clip*, const uint8_t*, size_t, float*) { return guarded([&] { fail(MI_ERR_UNSUPPORTED, "ViT path not built yet"); }); }
+
+namespace {
+
+// ------------------------------------------------------------------ safetensors
+struct TensorInfo {
+    std::string dtype;
+    std::vector<int64_t> shape;
+    uint64_t begin = 0, end = 0;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto d : shape) n *= d;
+        return n;
+    }
+};
+
+// Minimal JSON reader for the safetensors header (one object of objects).
+struct Json {
+    const char* p;
+    const char* e;
+    void ws() { while (p < e && std::isspace((unsigned char)*p)) ++p; }
+    void expect(char c) {
+        ws();
+        if (p >= e || *p != c) fail(MI_ERR_IO, "safetensors header: expected '%c'", c);
+        ++p;
+    }
+    bool peek(char c) { ws(); return p < e && *p == c; }
+    std::string str() {
+        expect('"');
+        std::string s;
+        while (p < e && *p != '"') {
+            if (*p == '\\' && p + 1 < e) { ++p; }
+            s.push_back(*p++);
+        }
+        expect('"');
+        return s;
+    }
+    int64_t num() {
+        ws();
+        char* end = nullptr;
+        const long long v = std::strtoll(p, &end, 10);
+        if (end == p) fail(MI_ERR_IO, "safetensors header: expected a number");
+        p = end;
+        return v;
+    }
+    void skip() {  // any value
+        ws();
+        if (peek('"')) { str(); return; }
+        if (peek('{')) { ++p; if (peek('}')) { ++p; return; } do { str(); expect(':'); skip(); } while (peek(',') && ++p); expect('}'); return; }
+        if (peek('[')) { ++p; if (peek(']')) { ++p; return; } do { skip(); } while (peek(',') && ++p); expect(']'); return; }
+        while (p < e && *p != ',' && *p != '}' && *p != ']') ++p;
+    }
+};
+
+struct SafeTensors {
+    FILE* f = nullptr;
+    uint64_t data_start = 0, file_size = 0;
+    std::map<std::string, TensorInfo> tensors;
+    std::map<std::string, std::string> meta;
+
+    explicit SafeTensors(const char* path) {
+        f = std::fopen(path, "rb");
+        if (!f) fail(MI_ERR_IO, "cannot open weights file '%s'", path);
+        std::fseek(f, 0, SEEK_END);
+        file_size = (uint64_t)std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        uint64_t hl = 0;
+        if (std::fread(&hl, 8, 1, f) != 1 || hl == 0 || hl > file_size - 8 || hl > (256u << 20))
+            fail(MI_ERR_IO, "'%s' is not a safetensors file (bad header length)", path);
+        std::string h(hl, '\0');
+        if (std::fread(&h[0], 1, hl, f) != hl) fail(MI_ERR_IO, "'%s': truncated header", path);
+        data_start = 8 + hl;
+        Json j{h.data(), h.data() + h.size()};
+        j.expect('{');
+        if (!j.peek('}')) {
+            do {
+                const std::string name = j.str();
+                j.expect(':');
+                if (name == "__metadata__") {
+                    j.expect('{');
+                    if (!j.peek('}')) do { std::string k = j.str(); j.expect(':'); meta[k] = j.str(); } while (j.peek(',') && ++j.p);
+                    j.expect('}');
+                    continue;
+                }
+                TensorInfo t;
+                j.expect('{');
+                do {
+                    const std::string key = j.str();
+                    j.expect(':');
+                    if (key == "dtype") t.dtype = j.str();
+                    else if (key == "shape") {
+                        j.expect('[');
+                        if (!j.peek(']')) do { t.shape.push_back(j.num()); } while (j.peek(',') && ++j.p);
+                        j.expect(']');
+                    } else if (key == "data_offsets") {
+                        j.expect('['); t.begin = (uint64_t)j.num(); j.expect(','); t.end = (uint64_t)j.num(); j.expect(']');
+                    } else j.skip();
+                } while (j.peek(',') && ++j.p);
+                j.expect('}');
+                if (data_start + t.end > file_size || t.begin > t.end)
+                    fail(MI_ERR_IO, "tensor '%s': data offsets outside the file", name.c_str());
+                tensors[name] = t;
+            } while (j.peek(',') && ++j.p);
+        }
+        j.expect('}');
+    }
+    ~SafeTensors() { if (f) std::fclose(f); }
+
+    const TensorInfo& info(const std::string& name) const {
+        auto it = tensors.find(name);
+        if (it == tensors.end()) fail(MI_ERR_IO, "weights file lacks tensor '%s'", name.c_str());
+        return it->second;
+    }
+    bool has(const std::string& name) const { return tensors.count(name) != 0; }
+
+    // tensor as fp32, checked against `numel`
+    std::vector<float> read(const std::string& name, int64_t numel) const {
+        const TensorInfo& t = info(name);
+        if (t.numel() != numel)
+            fail(MI_ERR_IO, "tensor '%s' has %lld elements, expected %lld", name.c_str(), (long long)t.numel(), (long long)numel);
+        const size_t esz = t.dtype == "F32" ? 4 : (t.dtype == "F16" || t.dtype == "BF16") ? 2 : 0;
+        if (!esz) fail(MI_ERR_UNSUPPORTED, "tensor '%s': dtype %s (F32/F16/BF16 supported)", name.c_str(), t.dtype.c_str());
+        if (t.end - t.begin != (uint64_t)numel * esz) fail(MI_ERR_IO, "tensor '%s': byte size mismatch", name.c_str());
+        std::vector<float> out((size_t)numel);
+        if (fseeko(f, (off_t)(data_start + t.begin), SEEK_SET) != 0) fail(MI_ERR_IO, "seek failed");
+        if (esz == 4) {
+            if (std::fread(out.data(), 4, (size_t)numel, f) != (size_t)numel) fail(MI_ERR_IO, "'%s': short read", name.c_str());
+        } else {
+            std::vector<uint16_t> raw((size_t)numel);
+            if (std::fread(raw.data(), 2, (size_t)numel, f) != (size_t)numel) fail(MI_ERR_IO, "'%s': short read", name.c_str());
+            if (t.dtype == "BF16") {
+                for (int64_t i = 0; i < numel; ++i) { uint32_t b = (uint32_t)raw[i] << 16; std::memcpy(&out[i], &b, 4); }
+            } else {
+                for (int64_t i = 0; i < numel; ++i) {  // IEEE half -> float
+                    const uint32_t hbits = raw[i], sign = (hbits & 0x8000u) << 16;
+                    uint32_t ex = (hbits >> 10) & 0x1f, man = hbits & 0x3ffu, b;
+                    if (ex == 0) {
+                        if (man == 0) b = sign;
+                        else { int sh = 0; while (!(man & 0x400u)) { man <<= 1; ++sh; } man &= 0x3ffu; b = sign | ((uint32_t)(113 - sh) << 23) | (man << 13); }
+                    } else if (ex == 31) b = sign | 0x7f800000u | (man << 13);
+                    else b = sign | ((ex + 112) << 23) | (man << 13);
+                    std::memcpy(&out[i], &b, 4);
+                }
+            }
+        }
+        return out;
+    }
+};
+
+inline uint16_t f32_to_bf16_host(float f) {  // round to nearest even, NaN stays NaN
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+
+// ------------------------------------------------------------------ model
+struct Layer {
+    float *ln1w, *ln1b, *ln2w, *ln2b;
+    void *wqkv, *wo, *w1, *w2;  // T [N][K]
+    float *bqkv, *bo, *b1, *b2;
+};
+
+}  // namespace
+
+struct mi_clip {
+    int device = 0, precision = 0;
+    int image = 0, patch = 0, grid = 0, S = 0, D = 0, L = 0, H = 0, FF = 0, E = 0, Kp = 0;
+    float eps = 1e-5f;
+    std::vector<void*> allocs;
+    float *cls = nullptr, *pos = nullptr, *pre_w = nullptr, *pre_b = nullptr, *post_w = nullptr, *post_b = nullptr,
+          *proj = nullptr;
+    void* wpatch = nullptr;  // T [D][Kp]
+    std::vector<Layer> layers;
+    // workspace for `cap` images
+    size_t cap = 0;
+    std::vector<void*> ws;
+    float *d_in = nullptr, *d_patch = nullptr, *d_x = nullptr, *d_out = nullptr;
+    void *d_col = nullptr, *d_y = nullptr, *d_qkv = nullptr, *d_h = nullptr;
+    uint8_t* d_rgb = nullptr;
+    hipStream_t stream = nullptr;
+    size_t max_batch = 256;
+    std::mutex mu;
+};
+
+namespace {
+
+size_t esize(const mi_clip* m) { return m->precision == MI_PRECISION_F32 ? 4 : 2; }
+
+template <typename T>
+T* dalloc(mi_clip* m, size_t n, std::vector<void*>& bag) {
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+    bag.push_back(p);
+    (void)m;
+    return static_cast<T*>(p);
+}
+
+float* upload_f32(mi_clip* m, const std::vector<float>& h) {
+    float* d = dalloc<float>(m, h.size(), m->allocs);
+    HIP_CHECK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    return d;
+}
+
+// GEMM operand in the model's precision
+void* upload_mat(mi_clip* m, const std::vector<float>& h) {
+    if (m->precision == MI_PRECISION_F32) return upload_f32(m, h);
+    std::vector<uint16_t> b(h.size());
+    for (size_t i = 0; i < h.size(); ++i) b[i] = f32_to_bf16_host(h[i]);
+    uint16_t* d = dalloc<uint16_t>(m, b.size(), m->allocs);
+    HIP_CHECK(hipMemcpy(d, b.data(), b.size() * 2, hipMemcpyHostToDevice));
+    return d;
+}
+
+void load_weights(mi_clip* m, const char* path) {
+    SafeTensors st(path);
+    const std::string v = "vision_model.";
+    const TensorInfo& pe = st.info(v + "embeddings.patch_embedding.weight");
+    if (pe.shape.size() != 4 || pe.shape[1] != 3 || pe.shape[2] != pe.shape[3])
+        fail(MI_ERR_UNSUPPORTED, "patch_embedding.weight must be [D,3,P,P]");
+    m->D = (int)pe.shape[0];
+    m->patch = (int)pe.shape[2];
+    const TensorInfo& po = st.info(v + "embeddings.position_embedding.weight");
+    if (po.shape.size() != 2 || po.shape[1] != m->D) fail(MI_ERR_UNSUPPORTED, "position_embedding.weight must be [S,D]");
+    m->S = (int)po.shape[0];
+    m->grid = (int)std::lround(std::sqrt((double)(m->S - 1)));
+    if (m->grid * m->grid + 1 != m->S) fail(MI_ERR_UNSUPPORTED, "token count %d is not G*G+1", m->S);
+    m->image = m->grid * m->patch;
+    int L = 0;
+    while (st.has(v + "encoder.layers." + std::to_string(L) + ".layer_norm1.weight")) ++L;
+    if (L == 0) fail(MI_ERR_IO, "no encoder layers found in '%s'", path);
+    m->L = L;
+    m->FF = (int)st.info(v + "encoder.layers.0.mlp.fc1.weight").shape.at(0);
+    m->E = (int)st.info("visual_projection.weight").shape.at(0);
+    m->H = m->D / 64;
+    auto it = st.meta.find("num_attention_heads");
+    if (it != st.meta.end()) m->H = std::atoi(it->second.c_str());
+    if (m->H <= 0 || m->D != m->H * 64)
+        fail(MI_ERR_UNSUPPORTED, "hidden %d with %d heads: the attention kernels are built for head_dim 64", m->D, m->H);
+    if (m->D % 128 != 0 || m->FF % 128 != 0)
+        fail(MI_ERR_UNSUPPORTED, "hidden (%d) and intermediate (%d) sizes must be multiples of 128", m->D, m->FF);
+    const int K = 3 * m->patch * m->patch;
+    m->Kp = (K + 63) / 64 * 64;
+
+    const int D = m->D, FF = m->FF;
+    m->cls = upload_f32(m, st.read(v + "embeddings.class_embedding", D));
+    m->pos = upload_f32(m, st.read(v + "embeddings.position_embedding.weight", (int64_t)m->S * D));
+    m->pre_w = upload_f32(m, st.read(v + "pre_layrnorm.weight", D));
+    m->pre_b = upload_f32(m, st.read(v + "pre_layrnorm.bias", D));
+    m->post_w = upload_f32(m, st.read(v + "post_layernorm.weight", D));
+    m->post_b = upload_f32(m, st.read(v + "post_layernorm.bias", D));
+    m->proj = upload_f32(m, st.read("visual_projection.weight", (int64_t)m->E * D));
+    {
+        const std::vector<float> w = st.read(v + "embeddings.patch_embedding.weight", (int64_t)D * K);
+        std::vector<float> wp((size_t)D * m->Kp, 0.0f);
+        for (int d = 0; d < D; ++d) std::memcpy(&wp[(size_t)d * m->Kp], &w[(size_t)d * K], (size_t)K * 4);
+        m->wpatch = upload_mat(m, wp);
+    }
+    m->layers.resize(L);
+    for (int i = 0; i < L; ++i) {
+        const std::string p = v + "encoder.layers." + std::to_string(i) + ".";
+        Layer& ly = m->layers[i];
+        ly.ln1w = upload_f32(m, st.read(p + "layer_norm1.weight", D));
+        ly.ln1b = upload_f32(m, st.read(p + "layer_norm1.bias", D));
+        ly.ln2w = upload_f32(m, st.read(p + "layer_norm2.weight", D));
+        ly.ln2b = upload_f32(m, st.read(p + "layer_norm2.bias", D));
+        std::vector<float> wqkv, bqkv;
+        for (const char* n : {"q_proj", "k_proj", "v_proj"}) {
+            const auto w = st.read(p + "self_attn." + n + ".weight", (int64_t)D * D);
+            const auto b = st.read(p + "self_attn." + n + ".bias", D);
+            wqkv.insert(wqkv.end(), w.begin(), w.end());
+            bqkv.insert(bqkv.end(), b.begin(), b.end());
+        }
+        ly.wqkv = upload_mat(m, wqkv);
+        ly.bqkv = upload_f32(m, bqkv);
+        ly.wo = upload_mat(m, st.read(p + "self_attn.out_proj.weight", (int64_t)D * D));
+        ly.bo = upload_f32(m, st.read(p + "self_attn.out_proj.bias", D));
+        ly.w1 = upload_mat(m, st.read(p + "mlp.fc1.weight", (int64_t)FF * D));
+        ly.b1 = upload_f32(m, st.read(p + "mlp.fc1.bias", FF));
+        ly.w2 = upload_mat(m, st.read(p + "mlp.fc2.weight", (int64_t)D * FF));
+        ly.b2 = upload_f32(m, st.read(p + "mlp.fc2.bias", D));
+    }
+}
+
+size_t pad256(size_t v) { return (v + 255) / 256 * 256; }
+
+void ensure_workspace(mi_clip* m, size_t n) {
+    if (n <= m->cap) return;
+    for (void* p : m->ws) HIP_CHECK(hipFree(p));
+    m->ws.clear();
+    m->cap = 0;
+    const size_t es = esize(m), Mp = pad256(n * m->S), Pp = pad256(n * (m->S - 1));
+    auto bytes = [&](size_t b) {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, b));
+        HIP_CHECK(hipMemsetAsync(p, 0, b, m->stream));
+        m->ws.push_back(p);
+        return p;
+    };
+    const size_t px = (size_t)m->image * m->image * 3;
+    m->d_in = (float*)bytes(n * px * 4);
+    m->d_rgb = (uint8_t*)bytes(n * px);
+    m->d_col = bytes(Pp * m->Kp * es);
+    m->d_patch = (float*)bytes(Pp * m->D * 4);
+    m->d_x = (float*)bytes(Mp * m->D * 4);
+    m->d_y = bytes(Mp * m->D * es);
+    m->d_qkv = bytes(Mp * 3 * m->D * es);
+    m->d_h = bytes(Mp * m->FF * es);
+    m->d_out = (float*)bytes(n * m->E * 4);
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    m->cap = n;
+}
+
+// ---- launches --------------------------------------------------------------------
+template <int EPI>
+void gemm_p(int precision, const void* X, const void* W, const float* bias, void* out, size_t Mrows, int N, int K,
+            int ldo, hipStream_t s) {
+    const size_t Mp = (Mrows + 127) / 128 * 128;
+    const unsigned blocks = (unsigned)((Mp / 128) * (N / 128));
+    if (N % 128 != 0) fail(MI_ERR_UNSUPPORTED, "GEMM N=%d is not a multiple of 128", N);
+    if (precision == MI_PRECISION_F32) {
+        if (K % 16 != 0) fail(MI_ERR_UNSUPPORTED, "GEMM K=%d is not a multiple of 16", K);
+        hipLaunchKernelGGL((gemm_f32_kernel<EPI>), dim3(blocks), dim3(256), 0, s, (const float*)X, (const float*)W, bias,
+                           (float*)out, N, K, ldo);
+    } else {
+        if (K % 64 != 0) fail(MI_ERR_UNSUPPORTED, "GEMM K=%d is not a multiple of 64", K);
+        static bool attr_done[4] = {false, false, false, false};
+        if (EPI == EPI_STORE_F32 || EPI == EPI_BIAS_RESID) {
+            auto kern = gemm_bf16_kernel<EPI, float>;
+            if (!attr_done[EPI]) { HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_done[EPI] = true; }
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 65536, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, N, K, ldo);
+        } else {
+            auto kern = gemm_bf16_kernel<EPI, bf16_t>;
+            if (!attr_done[EPI]) { HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_done[EPI] = true; }
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 65536, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, N, K, ldo);
+        }
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+template <int EPI>
+void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out, size_t Mrows, int N, int K, int ldo,
+          hipStream_t s) {
+    gemm_p<EPI>(m->precision, X, W, bias, out, Mrows, N, K, ldo, s);
+}
+
+// dispatch on the row width D = 64*VEC*NT
+#define MI_LN_DISPATCH(D, CALL)                                                              \
+    switch (D) {                                                                             \
+        case 128: { constexpr int VEC = 2, NT = 1; CALL; } break;                            \
+        case 256: { constexpr int VEC = 4, NT = 1; CALL; } break;                            \
+        case 384: { constexpr int VEC = 2, NT = 3; CALL; } break;                            \
+        case 512: { constexpr int VEC = 4, NT = 2; CALL; } break;                            \
+        case 768: { constexpr int VEC = 4, NT = 3; CALL; } break;                            \
+        case 1024: { constexpr int VEC = 4, NT = 4; CALL; } break;                           \
+        case 1280: { constexpr int VEC = 4, NT = 5; CALL; } break;                           \
+        case 1536: { constexpr int VEC = 4, NT = 6; CALL; } break;                           \
+        case 1664: { constexpr int VEC = 2, NT = 13; CALL; } break;                          \
+        default: fail(MI_ERR_UNSUPPORTED, "hidden size %d has no LayerNorm instantiation", D); \
+    }
+
+void layer_norm(mi_clip* m, const float* x, void* y, const float* w, const float* b, size_t rows, hipStream_t s) {
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    if (m->precision == MI_PRECISION_F32) {
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<float, VEC, NT>), dim3(blocks), dim3(256), 0, s, x, (float*)y, w, b, (int)rows, m->eps));
+    } else {
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT>), dim3(blocks), dim3(256), 0, s, x, (bf16_t*)y, w, b, (int)rows, m->eps));
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void attention(mi_clip* m, size_t n, hipStream_t s) {
+    if (m->precision == MI_PRECISION_F32) {
+        const unsigned blocks = (unsigned)(n * m->H * ((m->S + 63) / 64));
+        hipLaunchKernelGGL(attn_f32_kernel, dim3(blocks), dim3(64), 0, s, (const float*)m->d_qkv, (float*)m->d_y, m->S, m->D, m->H);
+    } else {
+        const unsigned blocks = (unsigned)(n * m->H);
+        const int sp = (m->S + 31) / 32 * 32;
+#define MI_ATTN(SP)                                                                                                  \
+    {                                                                                                                \
+        static bool done = false;                                                                                    \
+        if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)attn_bf16_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, SP * 256)); done = true; } \
+        hipLaunchKernelGGL((attn_bf16_kernel<SP>), dim3(blocks), dim3(256), SP * 256, s, (const bf16_t*)m->d_qkv, (bf16_t*)m->d_y, m->S, m->D, m->H); \
+    }
+        if (sp <= 32) MI_ATTN(32)
+        else if (sp <= 64) MI_ATTN(64)
+        else if (sp <= 224) MI_ATTN(224)
+        else if (sp <= 288) MI_ATTN(288)
+        else fail(MI_ERR_UNSUPPORTED, "bf16 attention is built for up to 288 tokens (got %d)", m->S);
+#undef MI_ATTN
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// the whole tower on n <= cap device-resident images
+void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t s) {
+    const int D = m->D, S = m->S, FF = m->FF;
+    const size_t M = n * S, P = n * (S - 1);
+    // patch embedding: gather -> GEMM [P,Kp] x [D,Kp]^T -> f32
+    {
+        const size_t total = P * m->Kp;
+        const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65535 * 4);
+        if (m->precision == MI_PRECISION_F32)
+            hipLaunchKernelGGL((im2col_kernel<float>), dim3(blocks), dim3(256), 0, s, d_img, (float*)m->d_col, (int)n, m->grid, m->patch, m->image, m->Kp);
+        else
+            hipLaunchKernelGGL((im2col_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, d_img, (bf16_t*)m->d_col, (int)n, m->grid, m->patch, m->image, m->Kp);
+        HIP_CHECK(hipGetLastError());
+        gemm<EPI_STORE_F32>(m, m->d_col, m->wpatch, nullptr, m->d_patch, P, D, m->Kp, D, s);
+    }
+    {
+        const unsigned blocks = (unsigned)((M + 3) / 4);
+        MI_LN_DISPATCH(D, hipLaunchKernelGGL((embed_ln_kernel<VEC, NT>), dim3(blocks), dim3(256), 0, s, m->d_patch, m->cls, m->pos, m->d_x, m->pre_w, m->pre_b, (int)M, S, m->eps));
+        HIP_CHECK(hipGetLastError());
+    }
+    for (const Layer& ly : m->layers) {
+        layer_norm(m, m->d_x, m->d_y, ly.ln1w, ly.ln1b, M, s);
+        gemm<EPI_BIAS>(m, m->d_y, ly.wqkv, ly.bqkv, m->d_qkv, M, 3 * D, D, 3 * D, s);
+        attention(m, n, s);
+        gemm<EPI_BIAS_RESID>(m, m->d_y, ly.wo, ly.bo, m->d_x, M, D, D, D, s);
+        layer_norm(m, m->d_x, m->d_y, ly.ln2w, ly.ln2b, M, s);
+        gemm<EPI_BIAS_QGELU>(m, m->d_y, ly.w1, ly.b1, m->d_h, M, FF, D, FF, s);
+        gemm<EPI_BIAS_RESID>(m, m->d_h, ly.w2, ly.b2, m->d_x, M, D, FF, D, s);
+    }
+    MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)n), dim3(256), 0, s, m->d_x, m->post_w, m->post_b, m->proj, d_out, S, m->E, m->eps));
+    HIP_CHECK(hipGetLastError());
+}
+
+void free_model(mi_clip* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    for (void* p : m->allocs) (void)hipFree(p);
+    for (void* p : m->ws) (void)hipFree(p);
+    delete m;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** out) {
+    mi_clip* m = nullptr;
+    const int rc = guarded([&] {
+        if (!out) fail(MI_ERR_INVALID, "out is null");
+        *out = nullptr;
+        if (!weights_path) fail(MI_ERR_INVALID, "weights_path is null");
+        if (precision != MI_PRECISION_F32 && precision != MI_PRECISION_BF16)
+            fail(MI_ERR_INVALID, "precision %d: use MI_PRECISION_F32 (0) or MI_PRECISION_BF16 (1)", precision);
+        DeviceGuard g(device);
+        m = new mi_clip();
+        m->device = device;
+        m->precision = precision;
+        if (const char* e = std::getenv("MI_CLIP_MAX_BATCH")) m->max_batch = std::max(1, std::atoi(e));
+        HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+        load_weights(m, weights_path);
+        *out = m;
+    });
+    if (rc != MI_OK && m) free_model(m);
+    return rc;
+}
+
+void mi_clip_free(mi_clip* m) { free_model(m); }
+
+int mi_clip_info(const mi_clip* m, uint32_t out[8]) {
+    return guarded([&] {
+        if (!m || !out) fail(MI_ERR_INVALID, "null argument");
+        const int v[8] = {m->image, m->patch, m->S, m->D, m->L, m->H, m->FF, m->E};
+        for (int i = 0; i < 8; ++i) out[i] = (uint32_t)v[i];
+    });
+}
+
+int mi_clip_embed_device(mi_clip* m, const float* d_nchw, size_t n, float* d_out, void* stream) {
+    return guarded([&] {
+        if (!m) fail(MI_ERR_INVALID, "null model handle");
+        if (n == 0) return;
+        if (!d_nchw || !d_out) fail(MI_ERR_INVALID, "null buffer");
+        std::lock_guard<std::mutex> l(m->mu);
+        DeviceGuard g(m->device);
+        hipStream_t s = stream ? (hipStream_t)stream : m->stream;
+        const size_t px = (size_t)m->image * m->image * 3;
+        const size_t chunk = std::min(n, m->max_batch);
+        if (chunk > m->cap) { HIP_CHECK(hipStreamSynchronize(s)); ensure_workspace(m, chunk); }
+        for (size_t i = 0; i < n; i += chunk) {
+            const size_t c = std::min(chunk, n - i);
+            forward(m, d_nchw + i * px, c, d_out + i * m->E, s);
+        }
+    });
+}
+
+int mi_clip_embed(mi_clip* m, const float* nchw, size_t n, float* out) {
+    return guarded([&] {
+        if (!m) fail(MI_ERR_INVALID, "null model handle");
+        if (n == 0) return;  // the reference forwards an empty chunk (server/src/clip.rs:112-118)
+        if (!nchw || !out) fail(MI_ERR_INVALID, "null buffer");
+        std::lock_guard<std::mutex> l(m->mu);
+        DeviceGuard g(m->device);
+        const size_t px = (size_t)m->image * m->image * 3;
+        const size_t chunk = std::min(n, m->max_batch);
+        ensure_workspace(m, chunk);
+        for (size_t i = 0; i < n; i += chunk) {
+            const size_t c = std::min(chunk, n - i);
+            HIP_CHECK(hipMemcpyAsync(m->d_in, nchw + i * px, c * px * 4, hipMemcpyHostToDevice, m->stream));
+            forward(m, m->d_in, c, m->d_out, m->stream);
+            HIP_CHECK(hipMemcpyAsync(out + i * m->E, m->d_out, c * m->E * 4, hipMemcpyDeviceToHost, m->stream));
+            HIP_CHECK(hipStreamSynchronize(m->stream));
+        }
+    });
+}
+
+int mi_clip_embed_rgb8(mi_clip* m, const uint8_t* rgb8, size_t n, float* out) {
+    return guarded([&] {
+        if (!m) fail(MI_ERR_INVALID, "null model handle");
+        if (n == 0) return;
+        if (!rgb8 || !out) fail(MI_ERR_INVALID, "null buffer");
+        std::lock_guard<std::mutex> l(m->mu);
+        DeviceGuard g(m->device);
+        const size_t plane = (size_t)m->image * m->image, px = plane * 3;
+        const size_t chunk = std::min(n, m->max_batch);
+        ensure_workspace(m, chunk);
+        for (size_t i = 0; i < n; i += chunk) {
+            const size_t c = std::min(chunk, n - i);
+            HIP_CHECK(hipMemcpyAsync(m->d_rgb, rgb8 + i * px, c * px, hipMemcpyHostToDevice, m->stream));
+            hipLaunchKernelGGL(preprocess_rgb8_kernel, dim3(1024), dim3(256), 0, m->stream, m->d_rgb, m->d_in, c * plane, plane);
+            HIP_CHECK(hipGetLastError());
+            forward(m, m->d_in, c, m->d_out, m->stream);
+            HIP_CHECK(hipMemcpyAsync(out + i * m->E, m->d_out, c * m->E * 4, hipMemcpyDeviceToHost, m->stream));
+            HIP_CHECK(hipStreamSynchronize(m->stream));
+        }
+    });
+}
+
+
+// ---- op-level entry points (include/mi355clip_ops.h): host buffers in fp32, the op runs
+// on the device in `precision`; used by the per-op parity tests.
+namespace {
+struct Scratch {
+    std::vector<void*> p;
+    ~Scratch() { for (void* q : p) (void)hipFree(q); }
+    void* bytes(size_t b) { void* q = nullptr; HIP_CHECK(hipMalloc(&q, std::max<size_t>(b, 16))); HIP_CHECK(hipMemset(q, 0, std::max<size_t>(b, 16))); p.push_back(q); return q; }
+    // host f32 [rows][cols] -> device T [rows_pad][cols]
+    void* up(int precision, const float* h, size_t rows, size_t cols, size_t rows_pad) {
+        void* d = bytes(rows_pad * cols * (precision == MI_PRECISION_F32 ? 4 : 2));
+        if (precision == MI_PRECISION_F32) HIP_CHECK(hipMemcpy(d, h, rows * cols * 4, hipMemcpyHostToDevice));
+        else {
+            std::vector<uint16_t> b(rows * cols);
+            for (size_t i = 0; i < b.size(); ++i) b[i] = f32_to_bf16_host(h[i]);
+            HIP_CHECK(hipMemcpy(d, b.data(), b.size() * 2, hipMemcpyHostToDevice));
+        }
+        return d;
+    }
+    void down(int precision, const void* d, float* h, size_t n) {
+        if (precision == MI_PRECISION_F32) { HIP_CHECK(hipMemcpy(h, d, n * 4, hipMemcpyDeviceToHost)); return; }
+        std::vector<uint16_t> b(n);
+        HIP_CHECK(hipMemcpy(b.data(), d, n * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)b[i] << 16; std::memcpy(&h[i], &u, 4); }
+    }
+};
+}  // namespace
+
+int mi_op_linear(int device, int precision, int epilogue, const float* x, const float* w, const float* bias,
+                 float* out, size_t m_rows, int n, int k) {
+    return guarded([&] {
+        if (!x || !w || !out) fail(MI_ERR_INVALID, "null buffer");
+        if (epilogue != EPI_STORE_F32 && !bias) fail(MI_ERR_INVALID, "bias is null");
+        DeviceGuard g(device);
+        Scratch sc;
+        const size_t mp = pad256(m_rows);
+        void* dx = sc.up(precision, x, m_rows, k, mp);
+        void* dw = sc.up(precision, w, n, k, n);
+        float* db = bias ? (float*)sc.up(MI_PRECISION_F32, bias, 1, n, 1) : nullptr;
+        const bool f32_out = epilogue == EPI_STORE_F32 || epilogue == EPI_BIAS_RESID;
+        void* dout = f32_out ? sc.up(MI_PRECISION_F32, out, m_rows, n, mp) : sc.bytes(mp * n * 4);
+        switch (epilogue) {
+            case EPI_STORE_F32: gemm_p<EPI_STORE_F32>(precision, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;
+            case EPI_BIAS: gemm_p<EPI_BIAS>(precision, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;
+            case EPI_BIAS_QGELU: gemm_p<EPI_BIAS_QGELU>(precision, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;
+            case EPI_BIAS_RESID: gemm_p<EPI_BIAS_RESID>(precision, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;
+            default: fail(MI_ERR_INVALID, "epilogue %d", epilogue);
+        }
+        HIP_CHECK(hipDeviceSynchronize());
+        sc.down(f32_out ? MI_PRECISION_F32 : precision, dout, out, m_rows * n);
+    });
+}
+
+int mi_op_attention(int device, int precision, const float* qkv, float* ctx, size_t n_img, int s_tok, int d, int heads) {
+    return guarded([&] {
+        if (!qkv || !ctx) fail(MI_ERR_INVALID, "null buffer");
+        if (d != heads * 64) fail(MI_ERR_UNSUPPORTED, "head_dim must be 64");
+        DeviceGuard g(device);
+        Scratch sc;
+        mi_clip m;
+        m.precision = precision; m.S = s_tok; m.D = d; m.H = heads;
+        const size_t rows = n_img * s_tok;
+        m.d_qkv = sc.up(precision, qkv, rows, 3 * (size_t)d, pad256(rows));
+        m.d_y = sc.bytes(pad256(rows) * d * 4);
+        attention(&m, n_img, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        sc.down(precision, m.d_y, ctx, rows * d);
+    });
+}
+
+int mi_op_layernorm(int device, int precision, const float* x, const float* w, const float* b, float* y, size_t rows,
+                    int d, float eps) {
+    return guarded([&] {
+        if (!x || !w || !b || !y) fail(MI_ERR_INVALID, "null buffer");
+        DeviceGuard g(device);
+        Scratch sc;
+        mi_clip m;
+        m.precision = precision; m.D = d; m.eps = eps;
+        float* dx = (float*)sc.up(MI_PRECISION_F32, x, rows, d, rows);
+        float* dw = (float*)sc.up(MI_PRECISION_F32, w, 1, d, 1);
+        float* db = (float*)sc.up(MI_PRECISION_F32, b, 1, d, 1);
+        void* dy = sc.bytes(rows * d * 4);
+        layer_norm(&m, dx, dy, dw, db, rows, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        sc.down(precision, dy, y, rows * d);
+    });
+}
+
+}  // extern "C"

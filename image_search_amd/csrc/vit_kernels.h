@@ -1,0 +1,632 @@
+// vit_kernels.h — device code of the CLIP vision tower (Seam A).
+//
+// Replaces `clip::clip_vit_large_patch14::Model::forward` (call site
+// server/src/clip.rs:118; graph = Xenova/clip-vit-large-patch14 vision_model.onnx,
+// clip/build.rs:10-11): conv patch-embed -> +CLS -> +pos -> pre-LN ->
+// L x [LN -> MHA -> +res -> LN -> fc1 -> QuickGELU -> fc2 -> +res] -> CLS ->
+// post-LN -> projection.  Bound: MFMA (96 % of the 162 GFLOP/image are the six
+// linear GEMMs per layer).
+//
+// Data layout in HBM (M = n*S token rows, padded to a multiple of 256):
+//   x    [M][D]   f32   residual stream (fp32 in both precisions)
+//   y    [M][D]   T     LayerNorm output / attention context
+//   qkv  [M][3D]  T     fused q|k|v projection (head h = columns h*64..h*64+63)
+//   hbuf [M][FF]  T     fc1 output after QuickGELU
+//   weights [N][K] T    exactly PyTorch's [out,in] = K-contiguous, so both MFMA
+//                       operands are read K-major with no transposition
+//   T = f32 (MI_PRECISION_F32, exact-f32 MFMA 32x32x2) or bf16 (MFMA 16x16x32).
+//
+// All GEMMs compute C^T tiles: the MFMA A operand is the WEIGHT tile (rows n) and
+// the B operand the ACTIVATION tile (rows m), so a lane ends up with 4 consecutive
+// output columns n of one token row m — an 8-byte (bf16) or 16-byte (f32)
+// contiguous store, and a float4 bias / residual access.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mi {
+
+typedef unsigned short bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+
+enum { EPI_STORE_F32 = 0, EPI_BIAS = 1, EPI_BIAS_QGELU = 2, EPI_BIAS_RESID = 3 };
+
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// x * sigmoid(1.702 x)  (transformers/activations.py:117-123)
+template <bool FAST>
+__device__ __forceinline__ float quick_gelu(float x) {
+    const float e = FAST ? __expf(-1.702f * x) : expf(-1.702f * x);
+    return x / (1.0f + e);
+}
+
+// ------------------------------------------------------------------ preprocessing
+// image_prepare_resnet's arithmetic (server/src/clip.rs:158-172) on the device:
+// rgb8 [n][H][W][3] -> chw f32 [n][3][H][W]; IEEE division, same bits as the host.
+__global__ void preprocess_rgb8_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ chw, size_t n_px,
+                                       size_t plane) {
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float sd[3] = {0.229f, 0.224f, 0.225f};
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_px; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t im = p / plane, i = p % plane;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = (float)rgb[p * 3 + c] / 255.0f;
+            chw[(im * 3 + c) * plane + i] = (v - mean[c]) / sd[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ patch gather
+// conv(stride = kernel = P, no bias) as a GEMM: col[b*G*G + gy*G + gx][k],
+// k = c*P*P + py*P + px (the flatten order of weight [D,3,P,P]); k >= 3*P*P is zero.
+template <typename T>
+__global__ void im2col_kernel(const float* __restrict__ img, T* __restrict__ col, int n, int G, int P, int HW,
+                              int Kp) {
+    const int PP = P * P, K = 3 * PP;
+    const size_t total = (size_t)n * G * G * Kp;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % Kp);
+        const size_t row = idx / Kp;
+        float v = 0.0f;
+        if (k < K) {
+            const int c = k / PP, rem = k % PP, py = rem / P, px = rem % P;
+            const int gx = (int)(row % G), gy = (int)((row / G) % G);
+            const size_t b = row / ((size_t)G * G);
+            v = img[((b * 3 + c) * HW + (size_t)(gy * P + py)) * HW + gx * P + px];
+        }
+        if constexpr (sizeof(T) == 4) col[idx] = v; else col[idx] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm
+// One wave per row, row held in registers, two-pass mean / biased variance,
+// y = d / sqrt(var + eps) * w + b  (the decomposed opset-16 form the reference
+// graph keeps: clip/scripts/upgrade_opset.py:9,23).  D = 64*VEC*NT.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int VEC>
+__device__ __forceinline__ void ld_vec(float* dst, const float* __restrict__ p) {
+    if constexpr (VEC == 4) {
+        const v4f t = *reinterpret_cast<const v4f*>(p);
+        dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+    } else if constexpr (VEC == 2) {
+        const v2f t = *reinterpret_cast<const v2f*>(p);
+        dst[0] = t.x; dst[1] = t.y;
+    } else {
+        dst[0] = *p;
+    }
+}
+template <int VEC, typename T>
+__device__ __forceinline__ void st_vec(T* __restrict__ p, const float* src) {
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (VEC == 4) *reinterpret_cast<v4f*>(p) = (v4f){src[0], src[1], src[2], src[3]};
+        else if constexpr (VEC == 2) *reinterpret_cast<v2f*>(p) = (v2f){src[0], src[1]};
+        else *p = src[0];
+    } else {
+        if constexpr (VEC == 4) *reinterpret_cast<v2u*>(p) = (v2u){pack2bf(src[0], src[1]), pack2bf(src[2], src[3])};
+        else if constexpr (VEC == 2) *reinterpret_cast<uint32_t*>(p) = pack2bf(src[0], src[1]);
+        else *p = f2bf(src[0]);
+    }
+}
+
+template <int VEC, int NT>
+struct LnRow {
+    float v[VEC * NT];
+    __device__ __forceinline__ void load(const float* __restrict__ p, int lane) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ld_vec<VEC>(&v[t * VEC], p + (t * 64 + lane) * VEC);
+    }
+    __device__ __forceinline__ void add(const float* __restrict__ p, int lane) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float u[VEC];
+            ld_vec<VEC>(u, p + (t * 64 + lane) * VEC);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) v[t * VEC + c] += u[c];
+        }
+    }
+    __device__ __forceinline__ void normalize(const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                              int lane) {
+        constexpr float inv = 1.0f / (64 * VEC * NT);
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < VEC * NT; ++j) s += v[j];
+        const float mean = wave_sum(s) * inv;
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < VEC * NT; ++j) { v[j] -= mean; q = __builtin_fmaf(v[j], v[j], q); }
+        const float sd = sqrtf(wave_sum(q) * inv + eps);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float ww[VEC], bb[VEC];
+            ld_vec<VEC>(ww, w + (t * 64 + lane) * VEC);
+            ld_vec<VEC>(bb, b + (t * 64 + lane) * VEC);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) v[t * VEC + c] = v[t * VEC + c] / sd * ww[c] + bb[c];
+        }
+    }
+    template <typename T>
+    __device__ __forceinline__ void store(T* __restrict__ p, int lane) const {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) st_vec<VEC, T>(p + (t * 64 + lane) * VEC, &v[t * VEC]);
+    }
+};
+
+// y[row] = LN(x[row]) for row < rows; 4 rows per 256-thread block
+template <typename T, int VEC, int NT>
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, T* __restrict__ y,
+                                                 const float* __restrict__ w, const float* __restrict__ b, int rows,
+                                                 float eps) {
+    constexpr int D = 64 * VEC * NT;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    LnRow<VEC, NT> r;
+    r.load(x + (size_t)row * D, lane);
+    r.normalize(w, b, eps, lane);
+    r.store(y + (size_t)row * D, lane);
+}
+
+// token assembly + pre-LN (modeling_clip.py:198-218, :641-651):
+// x[b*S+s] = LN_pre((s == 0 ? cls : patch[b*(S-1)+s-1]) + pos[s])
+template <int VEC, int NT>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, float* __restrict__ x,
+                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                       int rows, int S, float eps) {
+    constexpr int D = 64 * VEC * NT;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int bimg = row / S, s = row % S;
+    LnRow<VEC, NT> r;
+    r.load(s == 0 ? cls : patch + ((size_t)bimg * (S - 1) + (s - 1)) * D, lane);
+    r.add(pos + (size_t)s * D, lane);
+    r.normalize(w, b, eps, lane);
+    r.store(x + (size_t)row * D, lane);
+}
+
+// CLS pool + post-LN + bias-free projection (modeling_clip.py:641-651, :944-950):
+// out[b][e] = sum_d proj[e][d] * LN_post(x[b*S])[d].  One block per image.
+template <int VEC, int NT>
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ b, const float* __restrict__ proj,
+                                                   float* __restrict__ out, int S, int E, float eps) {
+    constexpr int D = 64 * VEC * NT;
+    __shared__ float pooled[D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        LnRow<VEC, NT> r;
+        r.load(x + (size_t)blockIdx.x * S * D, lane);
+        r.normalize(w, b, eps, lane);
+        r.store(pooled, lane);
+    }
+    __syncthreads();
+    for (int e = wave; e < E; e += 4) {
+        const float* pr = proj + (size_t)e * D;
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int d = lane; d < D; d += 64) acc = __builtin_fmaf(pr[d], pooled[d], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) out[(size_t)blockIdx.x * E + e] = acc;
+    }
+}
+
+// ------------------------------------------------------------------ epilogues
+// `v` = 4 consecutive output columns n..n+3 of token row m.
+template <int EPI, typename TO, bool FAST>
+__device__ __forceinline__ void epilogue4(v4f v, const float* __restrict__ bias, void* __restrict__ out, size_t m,
+                                          int n, int ldo) {
+    if constexpr (EPI != EPI_STORE_F32) {
+        const v4f bv = *reinterpret_cast<const v4f*>(bias + n);
+        v += bv;
+    }
+    if constexpr (EPI == EPI_BIAS_QGELU) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = quick_gelu<FAST>(v[c]);
+    }
+    if constexpr (EPI == EPI_STORE_F32) {
+        *reinterpret_cast<v4f*>(static_cast<float*>(out) + m * ldo + n) = v;
+    } else if constexpr (EPI == EPI_BIAS_RESID) {
+        v4f* p = reinterpret_cast<v4f*>(static_cast<float*>(out) + m * ldo + n);
+        *p = *p + v;
+    } else if constexpr (sizeof(TO) == 4) {
+        *reinterpret_cast<v4f*>(static_cast<float*>(out) + m * ldo + n) = v;
+    } else {
+        v2u pk;
+        pk.x = pack2bf(v[0], v[1]);
+        pk.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<v2u*>(static_cast<bf16_t*>(out) + m * ldo + n) = pk;
+    }
+}
+
+// ------------------------------------------------------------------ fp32 GEMM (parity path)
+// out[m][n] (+)= sum_k X[m][k] * W[n][k]; exact-f32 MFMA 32x32x2 (a k-ordered fmaf
+// chain, bit for bit).  128x128x16 tiles, 4 waves (2x2), each 64x64 = 2x2 MFMA tiles.
+// M % 128 == 0 (buffers are padded), N % 128 == 0, K % 16 == 0.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                       int K, int ldo) {
+    constexpr int LDT = 132;
+    __shared__ float Xs[2][16][LDT];
+    __shared__ float Ws[2][16][LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+    const int nt = N / 128;
+    const int tm = blockIdx.x / nt, tn = blockIdx.x % nt;
+    const size_t m0 = (size_t)tm * 128;
+    const int n0 = tn * 128;
+    const int r = tid >> 2, kq = tid & 3;
+    const float* xp = X + (m0 + r) * K + 4 * kq;
+    const float* wp = W + ((size_t)n0 + r) * K + 4 * kq;
+    v4f rx0, rx1, rw0, rw1;
+    auto gload = [&](int kt) {
+        rx0 = *reinterpret_cast<const v4f*>(xp + kt * 16);
+        rx1 = *reinterpret_cast<const v4f*>(xp + (size_t)64 * K + kt * 16);
+        rw0 = *reinterpret_cast<const v4f*>(wp + kt * 16);
+        rw1 = *reinterpret_cast<const v4f*>(wp + (size_t)64 * K + kt * 16);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            Xs[buf][4 * kq + c][r] = rx0[c]; Xs[buf][4 * kq + c][r + 64] = rx1[c];
+            Ws[buf][4 * kq + c][r] = rw0[c]; Ws[buf][4 * kq + c][r + 64] = rw1[c];
+        }
+    };
+    v16f acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.0f;
+
+    const int nk = K / 16;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = Ws[cur][2 * kk + h][wn * 64 + i * 32 + l31];
+                b[i] = Xs[cur][2 * kk + h][wm * 64 + i * 32 + l31];
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ni], b[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // C[i = n][j = m]: lane holds column j = lane&31, rows i = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v4f v = {acc[ni][mi][4 * q], acc[ni][mi][4 * q + 1], acc[ni][mi][4 * q + 2], acc[ni][mi][4 * q + 3]};
+                const size_t m = m0 + wm * 64 + mi * 32 + l31;
+                const int n = n0 + wn * 64 + ni * 32 + 8 * q + 4 * h;
+                epilogue4<EPI, float, false>(v, bias, out, m, n, ldo);
+            }
+}
+
+// ------------------------------------------------------------------ bf16 GEMM (throughput path)
+// 128x128x64 tiles, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles.
+// Both operand tiles go HBM -> LDS with global_load_lds_dwordx4 (1 KiB = 8 rows of
+// 128 B per wave-instruction, LDS image linear) into two 32 KiB buffers; the
+// ds_read_b128 bank conflicts of 128-byte rows are removed by an XOR swizzle of the
+// 16-byte chunk index with (row & 7), applied to the per-lane SOURCE address and
+// to the read address (the same involution on both sides).
+// M % 128 == 0, N % 128 == 0, K % 64 == 0.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// XCD-aware block id: blocks b and b+8 share an XCD (round-robin dispatch), so give
+// each XCD one contiguous chunk of the tile order (bijective for any grid size).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nb) {
+    const uint32_t q = nb >> 3, r = nb & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int EPI, typename TO>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                           const float* __restrict__ bias, void* __restrict__ out,
+                                                           int N, int K, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x (X 16 KiB | W 16 KiB)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, l15 = lane & 15;
+    const int nt = N / 128;
+    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = wg / nt, tn = wg % nt;
+    const size_t m0 = (size_t)tm * 128;
+    const int n0 = tn * 128;
+
+    // staging: wave w fills rows [32w, 32w+32) of both tiles, 4 wave-instructions each
+    const int rr = lane >> 3, p = lane & 7;
+    const unsigned char* xsrc =
+        reinterpret_cast<const unsigned char*>(X) + ((m0 + 32 * wave + rr) * K + 8 * (p ^ rr)) * 2;
+    const unsigned char* wsrc =
+        reinterpret_cast<const unsigned char*>(W) + (((size_t)n0 + 32 * wave + rr) * K + 8 * (p ^ rr)) * 2;
+    const size_t row8 = (size_t)8 * K * 2;
+    auto stage = [&](int buf, int kt) {
+        unsigned char* xb = smem + buf * 32768 + wave * 4096;
+        unsigned char* wb = xb + 16384;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(xsrc + j * row8 + (size_t)kt * 128, xb + j * 1024);
+            glds16(wsrc + j * row8 + (size_t)kt * 128, wb + j * 1024);
+        }
+    };
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+
+    // fragment addresses: row = (tile row) + l15 -> row & 7 == lane & 7
+    const int sw = lane & 7;
+    const int a_off = (wn * 64 + l15) * 128;  // W tile (MFMA A operand)
+    const int b_off = (wm * 64 + l15) * 128;  // X tile (MFMA B operand)
+    auto compute = [&](int buf) {
+        const unsigned char* xb = smem + buf * 32768;
+        const unsigned char* wb = xb + 16384;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ((4 * ks + g) ^ sw) << 4;
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *reinterpret_cast<const bf16x8*>(wb + a_off + i * 2048 + ch);
+                b[i] = *reinterpret_cast<const bf16x8*>(xb + b_off + i * 2048 + ch);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ni], b[mi], acc[ni][mi], 0, 0, 0);
+        }
+    };
+
+    const int nk = K / 64;
+    stage(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        stage(cur ^ 1, kt + 1);
+        compute(cur);
+        __syncthreads();
+        cur ^= 1;
+    }
+    compute(cur);
+
+    // C[i = n][j = m]: lane holds column j = lane&15, rows i = 4*(lane>>4) + e
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const size_t m = m0 + wm * 64 + mi * 16 + l15;
+            const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+            epilogue4<EPI, TO, true>(acc[ni][mi], bias, out, m, n, ldo);
+        }
+}
+
+// ------------------------------------------------------------------ attention, fp32 (parity path)
+// softmax(q k^T / 8) v per (image, head), one thread per query row, keys streamed
+// through LDS in chunks of 64, running max / sum (modeling_clip.py:259-277).
+__global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int S,
+                                                      int D, int H) {
+    __shared__ __attribute__((aligned(16))) float Ks[64][64];
+    __shared__ __attribute__((aligned(16))) float Vs[64][64];
+    const int tid = threadIdx.x;
+    const int nqt = (S + 63) / 64;
+    const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt;
+    const int b = bh / H, hh = bh % H;
+    const size_t ld = (size_t)3 * D;
+    const float* base = qkv + (size_t)b * S * ld + hh * 64;
+    const int qi = qt * 64 + tid;
+    const int qc = qi < S ? qi : S - 1;
+    float q[64], o[64];
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+        const v4f t = *reinterpret_cast<const v4f*>(base + (size_t)qc * ld + d);
+        q[d] = t.x * 0.125f; q[d + 1] = t.y * 0.125f; q[d + 2] = t.z * 0.125f; q[d + 3] = t.w * 0.125f;
+    }
+#pragma unroll
+    for (int d = 0; d < 64; ++d) o[d] = 0.0f;
+    float mx = -INFINITY, l = 0.0f;
+    for (int k0 = 0; k0 < S; k0 += 64) {
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int idx = tid + 64 * i, row = idx >> 4, c4 = (idx & 15) * 4;
+            v4f kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+            if (k0 + row < S) {
+                kv = *reinterpret_cast<const v4f*>(base + (size_t)(k0 + row) * ld + D + c4);
+                vv = *reinterpret_cast<const v4f*>(base + (size_t)(k0 + row) * ld + 2 * D + c4);
+            }
+            *reinterpret_cast<v4f*>(&Ks[row][c4]) = kv;
+            *reinterpret_cast<v4f*>(&Vs[row][c4]) = vv;
+        }
+        __syncthreads();
+        const int nk = min(64, S - k0);
+        for (int j = 0; j < nk; ++j) {
+            float s = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) s = __builtin_fmaf(q[d], Ks[j][d], s);
+            if (s > mx) {
+                const float c = expf(mx - s);
+                l *= c;
+#pragma unroll
+                for (int d = 0; d < 64; ++d) o[d] *= c;
+                mx = s;
+            }
+            const float pw = expf(s - mx);
+            l += pw;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) o[d] = __builtin_fmaf(pw, Vs[j][d], o[d]);
+        }
+    }
+    if (qi < S) {
+        float* dst = ctx + ((size_t)b * S + qi) * D + hh * 64;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            v4f t = {o[d] / l, o[d + 1] / l, o[d + 2] / l, o[d + 3] / l};
+            *reinterpret_cast<v4f*>(dst + d) = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ attention, bf16 MFMA
+// One workgroup per (image, head); K and V of the head ([S_PAD][64] bf16, 128-byte
+// rows, 16-byte chunks XOR-swizzled with row&7) stay in LDS; each wave walks query
+// tiles of 16 rows.  Scores are computed TRANSPOSED (S^T = K Q^T) so that a lane
+// owns one query column: softmax is an in-lane reduction plus two cross-lane steps,
+// and the exponentiated tile is already the A operand of P V (k-slot (g,e) of
+// step s = key 32s + 16(e>>2) + 4g + (e&3)); V is consumed through
+// ds_read_b64_tr_b16 so the same row-major image serves as the B operand.
+// S <= S_PAD, S_PAD % 32 == 0; the whole score row of a query lives in registers.
+template <int S_PAD>
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                        int S, int D, int H) {
+    constexpr int NKT = S_PAD / 16, NPV = S_PAD / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;
+    unsigned char* Vs = smem + S_PAD * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.x / H, hh = blockIdx.x % H;
+    const size_t ld = (size_t)3 * D;
+    const bf16_t* base = qkv + (size_t)b * S * ld + hh * 64;
+
+    for (int idx = tid; idx < S_PAD * 8; idx += 256) {
+        const int row = idx >> 3, c = idx & 7;
+        v4u kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+        if (row < S) {
+            kv = *reinterpret_cast<const v4u*>(base + (size_t)row * ld + D + c * 8);
+            vv = *reinterpret_cast<const v4u*>(base + (size_t)row * ld + 2 * D + c * 8);
+        }
+        const int off = row * 128 + ((c ^ (row & 7)) << 4);
+        *reinterpret_cast<v4u*>(Ks + off) = kv;
+        *reinterpret_cast<v4u*>(Vs + off) = vv;
+    }
+    __syncthreads();
+
+    const int nqt = (S + 15) / 16;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int qi = qt * 16 + l15;
+        const int qc = qi < S ? qi : S - 1;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * ld + 32 * ks + 8 * g);
+
+        v4f sc[NKT];
+#pragma unroll
+        for (int T = 0; T < NKT; ++T) {
+            sc[T] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int row = 16 * T + l15;
+                const bf16x8 kf =
+                    *reinterpret_cast<const bf16x8*>(Ks + row * 128 + (((4 * ks + g) ^ (row & 7)) << 4));
+                sc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[T], 0, 0, 0);
+            }
+        }
+        // sc[T][e] = (K Q^T)[key 16T + 4g + e][query l15]
+        float mx = -INFINITY;
+#pragma unroll
+        for (int T = 0; T < NKT; ++T)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = 16 * T + 4 * g + e;
+                const float v = key < S ? sc[T][e] * 0.125f : -INFINITY;
+                sc[T][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.0f;
+#pragma unroll
+        for (int T = 0; T < NKT; ++T)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pw = __expf(sc[T][e] - mx);
+                sc[T][e] = pw;
+                sum += pw;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+
+        v4f o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+        // transposed-read address of this lane inside its 16-lane group: row q, columns 4p..4p+3
+        const int tq = l15 >> 2, tp = l15 & 3;
+#pragma unroll
+        for (int s = 0; s < NPV; ++s) {
+            bf16x8 pa;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pa[e] = (__bf16)sc[2 * s][e];
+                pa[4 + e] = (__bf16)sc[2 * s + 1][e];
+            }
+            const int key0 = 32 * s + 4 * g + tq, key1 = key0 + 16;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int c = 2 * dt + (tp >> 1), sub = (tp & 1) * 8;
+                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(Vs + key0 * 128 + ((c ^ (key0 & 7)) << 4) + sub));
+                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(Vs + key1 * 128 + ((c ^ (key1 & 7)) << 4) + sub));
+                const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vf, o[dt], 0, 0, 0);
+            }
+        }
+        // o[dt][e] = O[query 4g + e][d = 16 dt + l15]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ie = __shfl(inv, 4 * g + e, 64);
+            const int qrow = qt * 16 + 4 * g + e;
+            if (qrow < S) {
+                bf16_t* dst = ctx + ((size_t)b * S + qrow) * D + hh * 64 + l15;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dst[16 * dt] = f2bf(o[dt][e] * ie);
+            }
+        }
+    }
+}
+
+}  // namespace mi
