@@ -149,12 +149,12 @@ def gather_and_merge(local_idx: np.ndarray, local_dist: np.ndarray, k: int, grou
     ld = torch.from_numpy(np.ascontiguousarray(local_dist, np.float32).reshape(nq, k))
     if dist.get_backend(group) == "nccl":
         li, ld = li.cuda(), ld.cuda()
-    gi = torch.empty((world,) + tuple(li.shape), dtype=li.dtype, device=li.device)
-    gd = torch.empty((world,) + tuple(ld.shape), dtype=ld.dtype, device=ld.device)
+    gi = torch.empty((world * nq, k), dtype=li.dtype, device=li.device)  # rank-major concatenation
+    gd = torch.empty((world * nq, k), dtype=ld.dtype, device=ld.device)
     dist.all_gather_into_tensor(gi, li, group=group)
     dist.all_gather_into_tensor(gd, ld, group=group)
-    gi = gi.cpu().numpy().view(np.uint64)  # [world, nq, k]
-    gd = gd.cpu().numpy()
+    gi = gi.cpu().numpy().view(np.uint64).reshape(world, nq, k)
+    gd = gd.cpu().numpy().reshape(world, nq, k)
     out_i = np.empty((nq, k), np.uint64)
     out_d = np.empty((nq, k), np.float32)
     for u in range(nq):

@@ -1,0 +1,135 @@
+"""Host logic and the C-ABI surface (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from image_search_amd import _lib, synth
+from image_search_amd.clip import image_prepare_resnet, is_image_path
+from image_search_amd.search import average_slices, merge_candidates, refine_query, shard_bounds
+from oracle.binding import orc_average_slices, orc_knn, orc_merge, orc_preprocess, orc_refine
+
+
+def test_library_exports_every_declared_symbol(mi):
+    declared = set()
+    inc = os.path.join(ROOT, "include")
+    for h in os.listdir(inc):
+        text = open(os.path.join(inc, h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 27
+    for name in sorted(declared):
+        assert hasattr(mi, name), f"{name} declared in include/ but not exported"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert mi.mi_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback(mi):
+    if mi.mi_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = ctypes.c_void_p()
+    assert mi.mi_knn_create(768, 0, ctypes.byref(h)) == -4  # MI_ERR_NO_DEVICE
+    assert b"no CPU fallback" in mi.mi_last_error()
+    assert mi.mi_clip_load(b"/nonexistent.safetensors", 0, 0, ctypes.byref(h)) == -4
+    assert not h.value
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "image_search_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "from oracle" not in text and "import oracle" not in text and "liboracle" not in text, f
+
+
+# ---- the reference's own unit tests, restated against the drop-in -----------------------
+
+def test_tes_average_vector(mi):
+    """server/src/search.rs:156-161 `tes_average_vector`."""
+    g = np.load(os.path.join(GOLDEN, "average_slices.npz"))
+    assert np.array_equal(average_slices([g["a"], g["b"]]), g["expect"])
+
+
+def test_test_matches(mi):
+    """server/src/clip.rs:181-233 `test_matches`."""
+    assert not is_image_path("file.txt")
+    assert is_image_path("file.jpg")
+    assert is_image_path("file.png")
+    assert not is_image_path("file.mp4")
+    assert not is_image_path("file")
+    assert is_image_path("/a/b.c/IMG_0001.JPEG") and is_image_path("x.TiFf") and not is_image_path(".png")
+
+
+def test_average_slices_asserts(mi):
+    with pytest.raises(AssertionError, match="Input must not be empty"):
+        average_slices([])
+    with pytest.raises(AssertionError, match="same length"):
+        average_slices([np.zeros(4, np.float32), np.zeros(5, np.float32)])
+    out = (ctypes.c_float * 4)()
+    assert mi.mi_average_slices(None, 0, 4, out) == -1
+    assert b"Input must not be empty" in mi.mi_last_error()
+
+
+def test_average_and_refine_match_oracle_bit_for_bit(mi, orc):
+    rng = np.random.default_rng(5)
+    for m in (1, 2, 3, 17):
+        vs = [(rng.standard_normal(768) * 10.0 ** int(rng.integers(-3, 4))).astype(np.float32) for _ in range(m)]
+        assert np.array_equal(average_slices(vs), orc_average_slices(orc, vs))
+        text = rng.standard_normal(768).astype(np.float32)
+        assert np.array_equal(refine_query(text, vs), orc_refine(orc, text, vs))
+    text = rng.standard_normal(768).astype(np.float32)
+    assert np.array_equal(refine_query(text, []), text)
+
+
+def test_preprocess_matches_oracle(mi, orc):
+    u8 = synth.images_u8(31, 3)
+    a = image_prepare_resnet(u8)
+    assert a.shape == (3, 3, 224, 224) and np.array_equal(a, orc_preprocess(orc, u8))
+    assert np.array_equal(image_prepare_resnet(u8[0]), a[0])
+
+
+def test_merge_matches_oracle_and_single_table(mi, orc):
+    rows = synth.corpus_rows(41, 0, 3000)
+    q = synth.corpus_rows(42, 0, 1)[0]
+    for k in (1, 10, 100):
+        lists_i, lists_d = [], []
+        for w in range(3):
+            lo, hi = shard_bounds(3000, 3, w)
+            i, d = orc_knn(orc, q, rows[lo:hi], k, base=lo)
+            lists_i.append(i); lists_d.append(d)
+        mi_i, mi_d = merge_candidates(np.stack(lists_i), np.stack(lists_d), k)
+        o_i, o_d = orc_merge(orc, np.stack(lists_i), np.stack(lists_d), k)
+        f_i, f_d = orc_knn(orc, q, rows, k)
+        assert np.array_equal(mi_i, o_i) and np.array_equal(mi_i, f_i)
+        assert np.array_equal(mi_d.view(np.uint32), f_d.view(np.uint32))
+    # short lists: missing entries are skipped and padded at the end
+    i = np.array([[5, 2 ** 64 - 1], [9, 7]], np.uint64)
+    d = np.array([[0.5, np.inf], [0.25, 0.5]], np.float32)
+    mi_i, mi_d = merge_candidates(i, d, 2)
+    assert mi_i.tolist() == [9, 5] and mi_d.tolist() == [0.25, 0.5]  # tie at 0.5 -> smaller id (5 < 7)
+    mi_i, mi_d = merge_candidates(i[:1], d[:1], 2)
+    assert mi_i.tolist() == [5, 2 ** 64 - 1] and np.isinf(mi_d[1])
+
+
+def test_shard_bounds_partition():
+    for n in (0, 1, 7, 80_000_000):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[r][1] == b[r + 1][0] for r in range(w - 1))
+    assert shard_bounds(80_000_000, 8, 3) == (30_000_000, 40_000_000)
+
+
+def test_safetensors_writer_roundtrip(tmp_path):
+    cfg = synth.VitConfig.tiny()
+    w = synth.vit_weights(cfg, 1)
+    p = str(tmp_path / "w.safetensors")
+    synth.save_safetensors(w, p, {"num_attention_heads": cfg.heads})
+    from safetensors.numpy import load_file
+    back = load_file(p)
+    assert set(back) == set(w)
+    assert all(np.array_equal(back[k], w[k]) for k in w)

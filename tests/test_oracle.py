@@ -1,0 +1,135 @@
+"""The oracle against every known answer there is for this path (CPU only).
+
+The reference pins exactly one number at this boundary — average_slices'
+known answer (server/src/search.rs:157-160); the ViT fixtures come from the
+locally installed transformers CLIP on seeded weights and the kNN fixtures from
+the fp32 order cross-checked in fp64 (oracle/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from image_search_amd import synth
+from oracle import vit_numpy
+from oracle.binding import (orc_average_slices, orc_cosine_dist, orc_cosine_dist_f64, orc_gen_f32, orc_knn,
+                            orc_merge, orc_preprocess, orc_refine)
+
+
+def test_average_slices_reference_known_answer(orc):
+    g = np.load(os.path.join(GOLDEN, "average_slices.npz"))
+    assert np.array_equal(orc_average_slices(orc, [g["a"], g["b"]]), g["expect"])
+
+
+def test_average_slices_empty_asserts_like_reference(orc):
+    with pytest.raises(ValueError, match="must not be empty"):
+        orc_average_slices(orc, [])
+
+
+def test_average_slices_order_and_division(orc):
+    rng = np.random.default_rng(3)
+    vs = [rng.standard_normal(768).astype(np.float32) for _ in range(7)]
+    acc = np.zeros(768, np.float32)
+    for v in vs:
+        acc += v
+    assert np.array_equal(orc_average_slices(orc, vs), acc / np.float32(7))
+
+
+def test_refine_is_mean_of_selected_mean_and_text(orc):
+    rng = np.random.default_rng(4)
+    text = rng.standard_normal(768).astype(np.float32)
+    sel = [rng.standard_normal(768).astype(np.float32) for _ in range(3)]
+    s = orc_average_slices(orc, sel)
+    assert np.array_equal(orc_refine(orc, text, sel), orc_average_slices(orc, [s, text]))
+    assert np.array_equal(orc_refine(orc, text, []), text)  # no marked image found: search.rs:28,60
+
+
+def test_generator_matches_numpy_and_golden(orc):
+    g = np.load(os.path.join(GOLDEN, "gen.npz"))
+    assert np.array_equal(synth.gen_f32(7, 0, 64), g["s7"])
+    assert np.array_equal(synth.gen_f32(7, 1 << 40, 64, 0.02), g["s7_off"])
+    assert np.array_equal(orc_gen_f32(orc, 7, 0, 64), g["s7"])
+    assert np.array_equal(orc_gen_f32(orc, 7, 1 << 40, 64, 0.02), g["s7_off"])
+    big = synth.gen_f32(3, 12345, 200_000)
+    assert np.array_equal(orc_gen_f32(orc, 3, 12345, 200_000), big)
+    assert abs(float(big.std()) - 1.0) < 0.01 and abs(float(big.mean())) < 0.01
+
+
+def test_preprocess_matches_reference_arithmetic(orc):
+    u8 = synth.images_u8(9, 2)
+    a = orc_preprocess(orc, u8)
+    assert np.array_equal(a, synth.preprocess_rgb8(u8))
+    # spot values: (p/255 - mean)/std in fp32, channel-major (clip.rs:164-172)
+    p = u8[1, 17, 33]
+    want = (np.float32(p[2]) / np.float32(255) - np.float32(0.406)) / np.float32(0.225)
+    assert a[1, 2, 17, 33] == want
+    assert a.min() > -2.2 and a.max() < 2.7
+
+
+def test_knn_oracle_matches_golden(orc):
+    g = np.load(os.path.join(GOLDEN, "knn.npz"))
+    for tag in ("n1k", "n100k"):
+        seed, qseed, n = [int(v) for v in g[f"{tag}_seed"]]
+        rows = synth.corpus_rows(seed, 0, n)
+        qs = synth.corpus_rows(qseed, 0, 4)
+        for k in (1, 10, 1000):
+            for u, q in enumerate(qs):
+                idx, dist = orc_knn(orc, q, rows, k)
+                assert np.array_equal(idx, g[f"{tag}_k{k}_idx"][u])
+                assert np.array_equal(dist.view(np.uint32), g[f"{tag}_k{k}_dist"][u].view(np.uint32))
+
+
+def test_knn_oracle_agrees_with_fp64_where_margins_allow(orc):
+    rows = synth.corpus_rows(21, 0, 5000)
+    q = synth.corpus_rows(22, 0, 1)[0]
+    d32 = orc_cosine_dist(orc, q, rows)
+    d64 = orc_cosine_dist_f64(orc, q, rows)
+    assert np.abs(d32 - d64).max() < 5e-7
+    idx, dist = orc_knn(orc, q, rows, 10)
+    order = np.lexsort((np.arange(5000), d64))[:11]
+    if np.diff(d64[order]).min() > 1e-6:
+        assert np.array_equal(idx.astype(np.int64), order[:10])
+    assert np.array_equal(dist, d32[idx.astype(np.int64)])
+
+
+def test_knn_oracle_edge_cases(orc):
+    rows = synth.corpus_rows(23, 0, 50)
+    rows[7] = rows[3]            # duplicate -> tie broken by id
+    rows[11] = 0.0               # zero-norm row -> NaN distance, sorts last
+    q = rows[3].copy()
+    idx, dist = orc_knn(orc, q, rows, 60, base=1000)
+    assert idx[0] == 1003 and idx[1] == 1007 and dist[0] == dist[1]
+    assert idx[49] == 1011 and np.isnan(dist[49])
+    assert np.all(idx[50:] == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(np.isinf(dist[50:]))
+    # merge of per-shard lists == single-table answer
+    a_i, a_d = orc_knn(orc, q, rows[:20], 8, base=0)
+    b_i, b_d = orc_knn(orc, q, rows[20:], 8, base=20)
+    m_i, m_d = orc_merge(orc, np.stack([a_i, b_i]), np.stack([a_d, b_d]), 8)
+    f_i, f_d = orc_knn(orc, q, rows, 8)
+    assert np.array_equal(m_i, f_i) and np.array_equal(m_d.view(np.uint32), f_d.view(np.uint32))
+
+
+def _vit_case(name, cfg):
+    g = np.load(os.path.join(GOLDEN, f"vit_{name}.npz"))
+    w = synth.vit_weights(cfg, int(g["seed"]))
+    px = synth.preprocess_rgb8(synth.images_u8(int(g["image_seed"]), int(g["n_img"]), cfg.image))
+    return g, w, px
+
+
+def test_vit_oracle_matches_transformers_golden_tiny():
+    cfg = synth.VitConfig.tiny()
+    g, w, px = _vit_case("tiny", cfg)
+    out = vit_numpy.vit_forward(w, cfg, px, np.float32)
+    rms = np.sqrt((g["embeds_f64"] ** 2).mean())
+    assert np.allclose(out, g["embeds_hf_f32"], rtol=1e-5, atol=1e-5 * rms)
+    assert np.allclose(out, g["embeds_f64"], rtol=1e-5, atol=1e-5 * rms)
+
+
+def test_vit_oracle_matches_transformers_golden_l14():
+    cfg = synth.VitConfig.vit_l14()
+    g, w, px = _vit_case("l14", cfg)
+    out = vit_numpy.vit_forward(w, cfg, px[:1], np.float32)
+    rms = np.sqrt((g["embeds_f64"] ** 2).mean())
+    assert out.shape == (1, 768)
+    assert np.allclose(out, g["embeds_hf_f32"][:1], rtol=2e-5, atol=2e-5 * rms)
+    assert sum(int(np.prod(s)) for _, s, _, _ in cfg.tensor_specs()) == 303_966_208
