@@ -126,7 +126,8 @@ static inline void orc_dot2(const float* q, const float* x, uint32_t dim, float*
 float orc_sumsq(const float* q, uint32_t dim) { float d, s; orc_dot2(q, q, dim, &d, &s); return s; }
 
 static inline float orc_dist(float dot, float qq, float xx) {
-    return 1.0f - dot / (sqrtf(qq) * sqrtf(xx));
+    const float d = 1.0f - dot / (sqrtf(qq) * sqrtf(xx));
+    return d != d ? __builtin_nanf("") : d; /* one NaN: +qNaN 0x7FC00000 (sign/payload carry no meaning) */
 }
 
 /* monotone u32 key of a distance: ascending key == ascending distance, NaN last */
