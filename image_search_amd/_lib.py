@@ -74,6 +74,14 @@ def lib() -> ctypes.CDLL:
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -m image_search_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64.so.7 and
+        # libhsa-runtime64; if ours (from /opt/rocm) is mapped first, torch later binds to a mixed
+        # set and reports "No HIP GPUs are available".  Loading torch first makes the dynamic linker
+        # resolve our DT_NEEDED libamdhip64.so.7 to the copy already mapped.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the .so lacks a declared symbol

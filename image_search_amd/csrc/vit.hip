@@ -194,6 +194,8 @@ struct mi_clip {
     std::vector<void*> ws;
     float *d_in = nullptr, *d_patch = nullptr, *d_x = nullptr, *d_out = nullptr;
     void *d_col = nullptr, *d_y = nullptr, *d_qkv = nullptr, *d_h = nullptr;
+    bf16_t* d_delta = nullptr;  // bf16 path: out_proj / fc2 output, added to x by the next LayerNorm
+    int n_cu = 256;
     uint8_t* d_rgb = nullptr;
     hipStream_t stream = nullptr;
     size_t max_batch = 256;
@@ -203,6 +205,8 @@ struct mi_clip {
 namespace {
 
 size_t esize(const mi_clip* m) { return m->precision == MI_PRECISION_F32 ? 4 : 2; }
+
+size_t pad256(size_t v) { return (v + 255) / 256 * 256; }
 
 template <typename T>
 T* dalloc(mi_clip* m, size_t n, std::vector<void*>& bag) {
@@ -299,7 +303,6 @@ void load_weights(mi_clip* m, const char* path) {
     }
 }
 
-size_t pad256(size_t v) { return (v + 255) / 256 * 256; }
 
 void ensure_workspace(mi_clip* m, size_t n) {
     if (n <= m->cap) return;
@@ -323,6 +326,7 @@ void ensure_workspace(mi_clip* m, size_t n) {
     m->d_y = bytes(Mp * m->D * es);
     m->d_qkv = bytes(Mp * 3 * m->D * es);
     m->d_h = bytes(Mp * m->FF * es);
+    m->d_delta = (bf16_t*)bytes(Mp * m->D * 2);
     m->d_out = (float*)bytes(n * m->E * 4);
     HIP_CHECK(hipStreamSynchronize(m->stream));
     m->cap = n;
@@ -355,9 +359,28 @@ void gemm_p(int precision, const void* X, const void* W, const float* bias, void
     HIP_CHECK(hipGetLastError());
 }
 
+// bf16 GEMM with bf16 output: the persistent 256x256 kernel when the shape allows, else 128x128
 template <int EPI>
 void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out, size_t Mrows, int N, int K, int ldo,
           hipStream_t s) {
+    const size_t Mp = pad256(Mrows);
+    const bool big = m->precision == MI_PRECISION_BF16 && (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) && N % 256 == 0 &&
+                     K % 64 == 0 && K >= 128 && Mp * (size_t)K * 2 < (1ull << 32) && Mp * (size_t)ldo * 2 < (1ull << 32) &&
+                     (size_t)N * K * 2 < (1ull << 32);
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) {
+        if (big) {
+            constexpr int LDS = 131072 + 18432 + 2048;
+            auto kern = gemm_bf16_persist_kernel<EPI, bf16_t>;
+            static bool done = false;
+            if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); done = true; }
+            const int n_tiles = (int)((Mp / 256) * (N / 256));
+            const int grid = std::min(n_tiles, m->n_cu);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, (int)Mp, N,
+                               K, ldo, n_tiles);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
     gemm_p<EPI>(m->precision, X, W, bias, out, Mrows, N, K, ldo, s);
 }
 
@@ -376,12 +399,13 @@ void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out
         default: fail(MI_ERR_UNSUPPORTED, "hidden size %d has no LayerNorm instantiation", D); \
     }
 
-void layer_norm(mi_clip* m, const float* x, void* y, const float* w, const float* b, size_t rows, hipStream_t s) {
+void layer_norm(mi_clip* m, float* x, const bf16_t* delta, void* y, const float* w, const float* b, size_t rows,
+                hipStream_t s) {
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     if (m->precision == MI_PRECISION_F32) {
-        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<float, VEC, NT>), dim3(blocks), dim3(256), 0, s, x, (float*)y, w, b, (int)rows, m->eps));
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<float, VEC, NT>), dim3(blocks), dim3(256), 0, s, x, delta, (float*)y, w, b, (int)rows, m->eps));
     } else {
-        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT>), dim3(blocks), dim3(256), 0, s, x, (bf16_t*)y, w, b, (int)rows, m->eps));
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT>), dim3(blocks), dim3(256), 0, s, x, delta, (bf16_t*)y, w, b, (int)rows, m->eps));
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -429,16 +453,29 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
         MI_LN_DISPATCH(D, hipLaunchKernelGGL((embed_ln_kernel<VEC, NT>), dim3(blocks), dim3(256), 0, s, m->d_patch, m->cls, m->pos, m->d_x, m->pre_w, m->pre_b, (int)M, S, m->eps));
         HIP_CHECK(hipGetLastError());
     }
+    // fp32 path: the residual add is the GEMM epilogue (x += acc + bias, fp32 read-modify-write).
+    // bf16 path: out_proj / fc2 store a bf16 `delta` (a pure, asynchronous store from the persistent
+    // GEMM) and the LayerNorm that follows — which streams x anyway — does x += delta.
+    const bool deferred = m->precision == MI_PRECISION_BF16;
+    const bf16_t* pending = nullptr;
     for (const Layer& ly : m->layers) {
-        layer_norm(m, m->d_x, m->d_y, ly.ln1w, ly.ln1b, M, s);
+        layer_norm(m, m->d_x, pending, m->d_y, ly.ln1w, ly.ln1b, M, s);
         gemm<EPI_BIAS>(m, m->d_y, ly.wqkv, ly.bqkv, m->d_qkv, M, 3 * D, D, 3 * D, s);
         attention(m, n, s);
-        gemm<EPI_BIAS_RESID>(m, m->d_y, ly.wo, ly.bo, m->d_x, M, D, D, D, s);
-        layer_norm(m, m->d_x, m->d_y, ly.ln2w, ly.ln2b, M, s);
-        gemm<EPI_BIAS_QGELU>(m, m->d_y, ly.w1, ly.b1, m->d_h, M, FF, D, FF, s);
-        gemm<EPI_BIAS_RESID>(m, m->d_h, ly.w2, ly.b2, m->d_x, M, D, FF, D, s);
+        if (deferred) {
+            gemm<EPI_BIAS>(m, m->d_y, ly.wo, ly.bo, m->d_delta, M, D, D, D, s);
+            layer_norm(m, m->d_x, m->d_delta, m->d_y, ly.ln2w, ly.ln2b, M, s);
+            gemm<EPI_BIAS_QGELU>(m, m->d_y, ly.w1, ly.b1, m->d_h, M, FF, D, FF, s);
+            gemm<EPI_BIAS>(m, m->d_h, ly.w2, ly.b2, m->d_delta, M, D, FF, D, s);
+            pending = m->d_delta;
+        } else {
+            gemm<EPI_BIAS_RESID>(m, m->d_y, ly.wo, ly.bo, m->d_x, M, D, D, D, s);
+            layer_norm(m, m->d_x, nullptr, m->d_y, ly.ln2w, ly.ln2b, M, s);
+            gemm<EPI_BIAS_QGELU>(m, m->d_y, ly.w1, ly.b1, m->d_h, M, FF, D, FF, s);
+            gemm<EPI_BIAS_RESID>(m, m->d_h, ly.w2, ly.b2, m->d_x, M, D, FF, D, s);
+        }
     }
-    MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)n), dim3(256), 0, s, m->d_x, m->post_w, m->post_b, m->proj, d_out, S, m->E, m->eps));
+    MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)n), dim3(256), 0, s, m->d_x, pending, m->post_w, m->post_b, m->proj, d_out, S, m->E, m->eps));
     HIP_CHECK(hipGetLastError());
 }
 
@@ -469,6 +506,9 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         m->precision = precision;
         if (const char* e = std::getenv("MI_CLIP_MAX_BATCH")) m->max_batch = std::max(1, std::atoi(e));
         HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        m->n_cu = prop.multiProcessorCount;
         load_weights(m, weights_path);
         *out = m;
     });
@@ -628,7 +668,7 @@ int mi_op_layernorm(int device, int precision, const float* x, const float* w, c
         float* dw = (float*)sc.up(MI_PRECISION_F32, w, 1, d, 1);
         float* db = (float*)sc.up(MI_PRECISION_F32, b, 1, d, 1);
         void* dy = sc.bytes(rows * d * 4);
-        layer_norm(&m, dx, dy, dw, db, rows, nullptr);
+        layer_norm(&m, dx, nullptr, dy, dw, db, rows, nullptr);
         HIP_CHECK(hipDeviceSynchronize());
         sc.down(precision, dy, y, rows * d);
     });

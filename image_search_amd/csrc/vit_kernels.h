@@ -142,6 +142,23 @@ struct LnRow {
             for (int c = 0; c < VEC; ++c) v[t * VEC + c] += u[c];
         }
     }
+    // v += bf16 row (the deferred residual of the previous GEMM, see vit.hip forward())
+    __device__ __forceinline__ void add_bf16(const bf16_t* __restrict__ p, int lane) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16_t* q = p + (t * 64 + lane) * VEC;
+            if constexpr (VEC == 4) {
+                const v2u u = *reinterpret_cast<const v2u*>(q);
+                v[t * 4 + 0] += __uint_as_float(u.x << 16); v[t * 4 + 1] += __uint_as_float(u.x & 0xffff0000u);
+                v[t * 4 + 2] += __uint_as_float(u.y << 16); v[t * 4 + 3] += __uint_as_float(u.y & 0xffff0000u);
+            } else if constexpr (VEC == 2) {
+                const uint32_t u = *reinterpret_cast<const uint32_t*>(q);
+                v[t * 2 + 0] += __uint_as_float(u << 16); v[t * 2 + 1] += __uint_as_float(u & 0xffff0000u);
+            } else {
+                v[t] += bf2f(*q);
+            }
+        }
+    }
     __device__ __forceinline__ void normalize(const float* __restrict__ w, const float* __restrict__ b, float eps,
                                               int lane) {
         constexpr float inv = 1.0f / (64 * VEC * NT);
@@ -169,17 +186,23 @@ struct LnRow {
     }
 };
 
-// y[row] = LN(x[row]) for row < rows; 4 rows per 256-thread block
+// y[row] = LN(x[row]) for row < rows; 4 rows per 256-thread block.  With `delta` (bf16 path):
+// x[row] += delta[row] first, written back — the residual add of the preceding out_proj / fc2,
+// whose GEMM epilogue is then a pure bf16 store.
 template <typename T, int VEC, int NT>
-__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, T* __restrict__ y,
-                                                 const float* __restrict__ w, const float* __restrict__ b, int rows,
-                                                 float eps) {
+__global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                 T* __restrict__ y, const float* __restrict__ w,
+                                                 const float* __restrict__ b, int rows, float eps) {
     constexpr int D = 64 * VEC * NT;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     LnRow<VEC, NT> r;
     r.load(x + (size_t)row * D, lane);
+    if (delta) {
+        r.add_bf16(delta + (size_t)row * D, lane);
+        r.store(x + (size_t)row * D, lane);
+    }
     r.normalize(w, b, eps, lane);
     r.store(y + (size_t)row * D, lane);
 }
@@ -206,15 +229,17 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
 // CLS pool + post-LN + bias-free projection (modeling_clip.py:641-651, :944-950):
 // out[b][e] = sum_d proj[e][d] * LN_post(x[b*S])[d].  One block per image.
 template <int VEC, int NT>
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                   const float* __restrict__ b, const float* __restrict__ proj,
-                                                   float* __restrict__ out, int S, int E, float eps) {
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                   const float* __restrict__ w, const float* __restrict__ b,
+                                                   const float* __restrict__ proj, float* __restrict__ out, int S,
+                                                   int E, float eps) {
     constexpr int D = 64 * VEC * NT;
     __shared__ float pooled[D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave == 0) {
         LnRow<VEC, NT> r;
         r.load(x + (size_t)blockIdx.x * S * D, lane);
+        if (delta) r.add_bf16(delta + (size_t)blockIdx.x * S * D, lane);
         r.normalize(w, b, eps, lane);
         r.store(pooled, lane);
     }
@@ -440,6 +465,398 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
             const int n = n0 + wn * 64 + ni * 16 + 4 * g;
             epilogue4<EPI, TO, true>(acc[ni][mi], bias, out, m, n, ldo);
         }
+}
+
+// ------------------------------------------------------------------ bf16 GEMM, 256x256x64 tiles
+// The large-M form: 8 waves (2 along m x 4 along n), each wave a 128(m) x 64(n) slab =
+// 8 x 4 MFMA 16x16x32 tiles (128 accumulator registers), 24 ds_read_b128 per 64 MFMAs.
+// LDS: 2 buffers x (X 256 rows x 128 B | W 256 rows x 128 B) = 128 KiB, one workgroup per CU.
+// Same staging (global_load_lds_dwordx4, source-side XOR swizzle) and fragment addressing as
+// the 128x128 kernel.  M % 256 == 0, N % 256 == 0, K % 64 == 0.
+template <int EPI, typename TO>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __restrict__ X,
+                                                               const bf16_t* __restrict__ W,
+                                                               const float* __restrict__ bias, void* __restrict__ out,
+                                                               int N, int K, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x (X 32 KiB | W 32 KiB)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, g = lane >> 4, l15 = lane & 15;
+    const int nt = N / 256;
+    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = wg / nt, tn = wg % nt;
+    const size_t m0 = (size_t)tm * 256;
+    const int n0 = tn * 256;
+
+    const int rr = lane >> 3, p = lane & 7;
+    const unsigned char* xsrc =
+        reinterpret_cast<const unsigned char*>(X) + ((m0 + 32 * wave + rr) * K + 8 * (p ^ rr)) * 2;
+    const unsigned char* wsrc =
+        reinterpret_cast<const unsigned char*>(W) + (((size_t)n0 + 32 * wave + rr) * K + 8 * (p ^ rr)) * 2;
+    const size_t row8 = (size_t)8 * K * 2;
+    auto stage = [&](int buf, int kt) {
+        unsigned char* xb = smem + buf * 65536 + wave * 4096;
+        unsigned char* wb = xb + 32768;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(xsrc + j * row8 + (size_t)kt * 128, xb + j * 1024);
+            glds16(wsrc + j * row8 + (size_t)kt * 128, wb + j * 1024);
+        }
+    };
+
+    v4f acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[a][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int sw = lane & 7;
+    const int a_off = 32768 + (wn * 64 + l15) * 128;  // W tile rows (MFMA A operand)
+    const int b_off = (wm * 128 + l15) * 128;          // X tile rows (MFMA B operand)
+    auto compute = [&](int buf) {
+        const unsigned char* base = smem + buf * 65536;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ((4 * ks + g) ^ sw) << 4;
+            bf16x8 a[4], b[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + ch);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) b[i] = *reinterpret_cast<const bf16x8*>(base + b_off + i * 2048 + ch);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ni], b[mi], acc[ni][mi], 0, 0, 0);
+        }
+    };
+
+    const int nk = K / 64;
+    stage(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        stage(cur ^ 1, kt + 1);
+        compute(cur);
+        __syncthreads();
+        cur ^= 1;
+    }
+    compute(cur);
+
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const size_t m = m0 + wm * 128 + mi * 16 + l15;
+            const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+            epilogue4<EPI, TO, true>(acc[ni][mi], bias, out, m, n, ldo);
+        }
+}
+
+// ------------------------------------------------------------------ bf16 GEMM, 256x256x64, pipelined
+// Same tile and wave layout as gemm_bf16_256_kernel, but the HBM/L2 -> LDS stream never
+// drains: each 64-deep K tile is staged as four 16 KiB half-tiles (X rows of quadrant-row
+// 0 / 1, W rows of quadrant-column 0 / 1), one half-tile per phase, running four phases
+// ahead of its first use; a phase computes one 64(m) x 32(n) quadrant of every wave's slab
+// (16 MFMA) in the snake order (0,0) (0,1) (1,1) (1,0) so the X / W fragments of the shared
+// half stay in registers.  Waits are counted (s_waitcnt vmcnt(4) leaves two half-tiles in
+// flight) and the barrier is the raw s_barrier, because __syncthreads() would drain the
+// LDS-DMA queue (cdna_hip_programming.md §5 "Pipelining across barriers").
+// LDS: 2 buffers x [XH0 | XH1 | WH0 | WH1] x 16 KiB = 128 KiB.
+//   XH[h] LDS row 64*wm + r  = tile row 128*wm + 64*h + r   (r < 64)
+//   WH[h] LDS row 32*wn + r  = tile row  64*wn + 32*h + r   (r < 32)
+template <int EPI, typename TO>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256p_kernel(const bf16_t* __restrict__ X,
+                                                                const bf16_t* __restrict__ W,
+                                                                const float* __restrict__ bias, void* __restrict__ out,
+                                                                int N, int K, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, g = lane >> 4, l15 = lane & 15;
+    const int nt = N / 256;
+    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = wg / nt, tn = wg % nt;
+    const size_t m0 = (size_t)tm * 256;
+    const int n0 = tn * 256;
+
+    // staging: wave w fills LDS rows [16w, 16w+16) of every half-tile (2 wave-instructions)
+    const int rr = lane >> 3, p = lane & 7;
+    const size_t Kb = (size_t)K * 2;
+    const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(X) +
+                                (m0 + 128 * (wave >> 2) + 16 * (wave & 3) + rr) * Kb + 16 * (p ^ rr);
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(W) +
+                                ((size_t)n0 + 64 * (wave >> 1) + 16 * (wave & 1) + rr) * Kb + 16 * (p ^ rr);
+    // half-tile index i: 0 = XH0, 1 = WH0, 2 = WH1, 3 = XH1 (order of first use)
+    auto stage_half = [&](int buf, int kt, int i) {
+        const bool is_x = (i == 0 || i == 3);
+        const int h = (i >= 2) ? 1 : 0;
+        unsigned char* dst = smem + buf * 65536 + (is_x ? 0 : 32768) + h * 16384 + wave * 2048;
+        const unsigned char* src = (is_x ? xsrc + (size_t)64 * h * Kb : wsrc + (size_t)32 * h * Kb) + (size_t)kt * 128;
+        glds16(src, dst);
+        glds16(src + 8 * Kb, dst + 1024);
+    };
+
+    v4f acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[a][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int sw = lane & 7;
+    const int x_off = (wm * 64 + l15) * 128;          // + mh*16384 + i*2048
+    const int w_off = 32768 + (wn * 32 + l15) * 128;  // + nh*16384 + i*2048
+    bf16x8 xf[2][4], wf[2][2];                         // [ks][tile]
+    auto load_x = [&](const unsigned char* base, int mh) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xf[ks][i] = *reinterpret_cast<const bf16x8*>(base + x_off + mh * 16384 + i * 2048 + (((4 * ks + g) ^ sw) << 4));
+    };
+    auto load_w = [&](const unsigned char* base, int nh) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                wf[ks][i] = *reinterpret_cast<const bf16x8*>(base + w_off + nh * 16384 + i * 2048 + (((4 * ks + g) ^ sw) << 4));
+    };
+#define MI_QUADRANT(MH, NH)                                                                                   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          _Pragma("unroll") for (int im = 0; im < 4; ++im)                                                          _Pragma("unroll") for (int in = 0; in < 2; ++in)                                                              acc[2 * NH + in][4 * MH + im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                      wf[ks][in], xf[ks][im], acc[2 * NH + in][4 * MH + im], 0, 0, 0);
+#define MI_PHASE_SYNC(N)                                       asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");     __builtin_amdgcn_s_barrier();
+
+    const int nk = K / 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_half(0, 0, i);
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int b = kt & 1;
+        const unsigned char* base = smem + b * 65536;
+        MI_PHASE_SYNC(4)
+        stage_half(b ^ 1, kt + 1, 0);
+        load_x(base, 0); load_w(base, 0);
+        MI_QUADRANT(0, 0)
+        MI_PHASE_SYNC(4)
+        stage_half(b ^ 1, kt + 1, 1);
+        load_w(base, 1);
+        MI_QUADRANT(0, 1)
+        MI_PHASE_SYNC(4)
+        stage_half(b ^ 1, kt + 1, 2);
+        load_x(base, 1);
+        MI_QUADRANT(1, 1)
+        MI_PHASE_SYNC(4)
+        stage_half(b ^ 1, kt + 1, 3);
+        load_w(base, 0);
+        MI_QUADRANT(1, 0)
+    }
+    {
+        const unsigned char* base = smem + ((nk - 1) & 1) * 65536;
+        MI_PHASE_SYNC(4)
+        load_x(base, 0); load_w(base, 0);
+        MI_QUADRANT(0, 0)
+        MI_PHASE_SYNC(2)
+        load_w(base, 1);
+        MI_QUADRANT(0, 1)
+        MI_PHASE_SYNC(0)
+        load_x(base, 1);
+        MI_QUADRANT(1, 1)
+        load_w(base, 0);
+        MI_QUADRANT(1, 0)
+    }
+#undef MI_QUADRANT
+#undef MI_PHASE_SYNC
+
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const size_t m = m0 + wm * 128 + mi * 16 + l15;
+            const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+            epilogue4<EPI, TO, true>(acc[ni][mi], bias, out, m, n, ldo);
+        }
+}
+
+// ------------------------------------------------------------------ bf16 GEMM, persistent form
+// gemm_bf16_256p_kernel's pipeline made persistent: gridDim.x <= #CUs workgroups each walk
+// tiles lb, lb+G, ...; the half-tile stream simply continues across the tile boundary (the
+// first K tile of the next tile is staged during the last K tile of the current one) and
+// the epilogue's 16 stores per lane are left in flight, counted, while the next tile
+// computes (vmcnt counts loads, stores and LDS-DMA together in issue order: the first K tile
+// after an epilogue waits vmcnt(4+16+1 bias DMA)) — instead of every CU draining its 128 KiB of output
+// at the same moment.  All addressing is SGPR descriptor + 32-bit offsets (buffer_load ... lds,
+// buffer_store): one VGPR per operand for the per-lane part, everything per-tile is scalar.
+// Operands and the output must each be < 4 GiB.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void glds16_buf(rsrc_t r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff,
+                                             0, 0);
+}
+
+template <int EPI, typename TO>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t* __restrict__ X,
+                                                                   const bf16_t* __restrict__ W,
+                                                                   const float* __restrict__ bias,
+                                                                   void* __restrict__ out, int M, int N, int K,
+                                                                   int ldo, int n_tiles) {
+    static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU, "the persistent form stores bf16 with bias");
+    static_assert(sizeof(TO) == 2, "bf16 output");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 128 KiB staging + 18 KiB patches + 2 KiB bias
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, g = lane >> 4, l15 = lane & 15;
+    const int nt = N / 256;
+    const int G = gridDim.x;
+    int tile = (int)xcd_remap(blockIdx.x, G);
+    if (tile >= n_tiles) return;
+
+    const uint32_t Kb = (uint32_t)K * 2;
+    const rsrc_t xr = make_rsrc(X, (uint32_t)M * Kb);
+    const rsrc_t wr = make_rsrc(W, (uint32_t)N * Kb);
+    const rsrc_t orr = make_rsrc(out, (uint32_t)M * (uint32_t)ldo * (uint32_t)sizeof(TO));
+    const int rr = lane >> 3, p = lane & 7;
+    const uint32_t x_lane = (uint32_t)rr * Kb + 16 * (p ^ rr);  // per-lane part (same for X and W)
+    const uint32_t x_wave = (uint32_t)(128 * (wave >> 2) + 16 * (wave & 3)) * Kb;
+    const uint32_t w_wave = (uint32_t)(64 * (wave >> 1) + 16 * (wave & 1)) * Kb;
+    // half-tile i: 0 = XH0, 1 = WH0, 2 = WH1, 3 = XH1;  xs / ws = scalar byte offset of the tile's first row
+    auto stage_half = [&](int buf, uint32_t xs, uint32_t ws, int kt, int i) {
+        const bool is_x = (i == 0 || i == 3);
+        const int h = (i >= 2) ? 1 : 0;
+        unsigned char* dst = smem + buf * 65536 + (is_x ? 0 : 32768) + h * 16384 + wave * 2048;
+        const uint32_t so = (is_x ? xs + x_wave + 64u * h * Kb : ws + w_wave + 32u * h * Kb) + (uint32_t)kt * 128u;
+        glds16_buf(is_x ? xr : wr, x_lane, so, dst);
+        glds16_buf(is_x ? xr : wr, x_lane, so + 8u * Kb, dst + 1024);
+    };
+
+    const int sw = lane & 7;
+    const int x_off = (wm * 64 + l15) * 128;
+    const int w_off = 32768 + (wn * 32 + l15) * 128;
+    bf16x8 xf[2][4], wf[2][2];
+    v4f acc[4][8];
+    auto load_x = [&](const unsigned char* base, int mh) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xf[ks][i] = *reinterpret_cast<const bf16x8*>(base + x_off + mh * 16384 + i * 2048 + (((4 * ks + g) ^ sw) << 4));
+    };
+    auto load_w = [&](const unsigned char* base, int nh) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                wf[ks][i] = *reinterpret_cast<const bf16x8*>(base + w_off + nh * 16384 + i * 2048 + (((4 * ks + g) ^ sw) << 4));
+    };
+#define MI_QUADRANT(MH, NH)                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
+    _Pragma("unroll") for (int im = 0; im < 4; ++im)                                                      \
+    _Pragma("unroll") for (int in = 0; in < 2; ++in)                                                      \
+        acc[2 * NH + in][4 * MH + im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
+            wf[ks][in], xf[ks][im], acc[2 * NH + in][4 * MH + im], 0, 0, 0);
+// wait mode (wave-uniform): 0 steady state, 1 first K tile after an epilogue (16 stores still
+// counted), 2 the very last K tile of this workgroup (nothing more is staged: 4, 2, 0)
+#define MI_SYNC(PH)                                                                            \
+    if (mode == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                             \
+    else if (mode == 1) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");                       \
+    else if (PH == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                          \
+    else if (PH == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                          \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+    __builtin_amdgcn_s_barrier();
+#define MI_STAGE(i) if (do_stage) stage_half(b ^ 1, s_x, s_w, s_kt, i);
+
+    // the wave's 64 bias values travel by LDS-DMA too (no VGPR destination: hipcc would drain the
+    // whole queue with vmcnt(0) at the first use of an ordinary load issued beside LDS-DMA)
+    const rsrc_t br = make_rsrc(bias, (uint32_t)N * 4u);
+    unsigned char* bias_lds = smem + 131072 + 18432 + wave * 256;
+    auto stage_bias = [&](int t) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (__attribute__((address_space(3))) void*)bias_lds, 4,
+                                                 (uint32_t)lane * 4u, (uint32_t)((t % nt) * 256 + wn * 64) * 4u, 0, 0);
+    };
+    const int nk = K / 64;
+    int b = 0, kt = 0;
+    uint32_t xs = (uint32_t)(tile / nt) * 256u * Kb, ws = (uint32_t)(tile % nt) * 256u * Kb;
+    stage_bias(tile);  // oldest op of the stream
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_half(0, xs, ws, 0, i);
+    bool after_epilogue = false;
+    // per-lane part of the output offset: row wm*128 + (lane>>3), column wn*64 + 8*(lane&7)
+    const uint32_t o_lane = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[a][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (;;) {
+        const bool last_kt = (kt == nk - 1);
+        const int next = tile + G;
+        const bool has_next = next < n_tiles;
+        // what the four phases of this K tile stage: the next K tile of this tile, or K tile 0 of the next
+        const uint32_t s_x = last_kt ? (uint32_t)(next / nt) * 256u * Kb : xs;
+        const uint32_t s_w = last_kt ? (uint32_t)(next % nt) * 256u * Kb : ws;
+        const int s_kt = last_kt ? 0 : kt + 1;
+        const bool do_stage = !last_kt || has_next;
+        const int mode = !do_stage ? 2 : ((after_epilogue && kt == 0) ? 1 : 0);
+        {
+            const unsigned char* base = smem + b * 65536;
+            MI_SYNC(0) MI_STAGE(0) load_x(base, 0); load_w(base, 0); MI_QUADRANT(0, 0)
+            MI_SYNC(1) MI_STAGE(1) load_w(base, 1); MI_QUADRANT(0, 1)
+            MI_SYNC(2) MI_STAGE(2) load_x(base, 1); MI_QUADRANT(1, 1)
+            MI_STAGE(3) load_w(base, 0); MI_QUADRANT(1, 0)
+            b ^= 1;
+        }
+        if (!last_kt) { ++kt; continue; }
+
+        // epilogue: each 16-row m-tile of the wave's slab goes through a wave-private LDS patch
+        // (16 rows x 144 B, beyond the two staging buffers) so that the global stores are whole
+        // 128-byte row segments, 16 bytes per lane: exactly 16 stores per lane, left in flight.
+        __builtin_amdgcn_sched_barrier(0);
+        const int n0 = (tile % nt) * 256;
+        const uint32_t o_tile = ((uint32_t)(tile / nt) * 256u * (uint32_t)ldo + (uint32_t)n0) * 2u;
+        v4f bv[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bv[ni] = *reinterpret_cast<const v4f*>(bias_lds + (ni * 16 + 4 * g) * 4);
+        unsigned char* patch = smem + 131072 + wave * 2304;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                v4f v = acc[ni][mi] + bv[ni];
+                acc[ni][mi] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                if constexpr (EPI == EPI_BIAS_QGELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = quick_gelu<true>(v[c]);
+                }
+                v2u pk;
+                pk.x = pack2bf(v[0], v[1]);
+                pk.y = pack2bf(v[2], v[3]);
+                *reinterpret_cast<v2u*>(patch + l15 * 144 + (ni * 16 + 4 * g) * 2) = pk;
+            }
+            // lanes exchange data through the patch: the ds_writes must have landed before any lane's
+            // ds_read, and the reads must have returned before the next m-tile's writes (without these
+            // waits 1e-6 of the outputs came out stale under store pressure — measured, N >= 3072)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = j * 8 + (lane >> 3);
+                const v4u d = *reinterpret_cast<const v4u*>(patch + row * 144 + (lane & 7) * 16);
+                const uint32_t so = o_tile + (uint32_t)(mi * 16 + j * 8) * (uint32_t)ldo * 2u;
+                __builtin_amdgcn_raw_buffer_store_b128(d, orr, o_lane, so, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!has_next) break;
+        tile = next;
+        xs = s_x; ws = s_w;
+        kt = 0;
+        after_epilogue = true;
+        stage_bias(tile);  // one more counted op between the stores and the next K tile
+    }
+#undef MI_QUADRANT
+#undef MI_SYNC
+#undef MI_STAGE
 }
 
 // ------------------------------------------------------------------ attention, fp32 (parity path)
