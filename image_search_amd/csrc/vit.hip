@@ -417,16 +417,19 @@ void attention(mi_clip* m, size_t n, hipStream_t s) {
     } else {
         const unsigned blocks = (unsigned)(n * m->H);
         const int sp = (m->S + 31) / 32 * 32;
-#define MI_ATTN(SP)                                                                                                  \
+#define MI_ATTN(SP, SC)                                                                                              \
     {                                                                                                                \
         static bool done = false;                                                                                    \
-        if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)attn_bf16_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, SP * 256)); done = true; } \
-        hipLaunchKernelGGL((attn_bf16_kernel<SP>), dim3(blocks), dim3(256), SP * 256, s, (const bf16_t*)m->d_qkv, (bf16_t*)m->d_y, m->S, m->D, m->H); \
+        if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)attn_bf16_kernel<SP, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, SP * 256 + 8192)); done = true; } \
+        hipLaunchKernelGGL((attn_bf16_kernel<SP, SC>), dim3(blocks), dim3(256), SP * 256 + 8192, s, (const bf16_t*)m->d_qkv, (bf16_t*)m->d_y, m->S, m->D, m->H); \
     }
-        if (sp <= 32) MI_ATTN(32)
-        else if (sp <= 64) MI_ATTN(64)
-        else if (sp <= 224) MI_ATTN(224)
-        else if (sp <= 288) MI_ATTN(288)
+        if (m->S == 257) MI_ATTN(288, 257)       // ViT-L/14, ViT-H/14 @224
+        else if (m->S == 197) MI_ATTN(224, 197)  // ViT-B/16 @224
+        else if (m->S == 50) MI_ATTN(64, 50)     // ViT-B/32 @224
+        else if (sp <= 32) MI_ATTN(32, 0)
+        else if (sp <= 64) MI_ATTN(64, 0)
+        else if (sp <= 224) MI_ATTN(224, 0)
+        else if (sp <= 288) MI_ATTN(288, 0)
         else fail(MI_ERR_UNSUPPORTED, "bf16 attention is built for up to 288 tokens (got %d)", m->S);
 #undef MI_ATTN
     }

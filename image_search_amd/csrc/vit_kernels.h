@@ -49,10 +49,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // x * sigmoid(1.702 x)  (transformers/activations.py:117-123)
+// FAST (bf16 path): v_exp_f32 + v_rcp_f32 (1 ulp each, far below bf16 resolution) instead of the
+// correctly rounded expf and IEEE division of the fp32 parity path.
 template <bool FAST>
 __device__ __forceinline__ float quick_gelu(float x) {
-    const float e = FAST ? __expf(-1.702f * x) : expf(-1.702f * x);
-    return x / (1.0f + e);
+    if constexpr (FAST) {
+        const float e = __builtin_amdgcn_exp2f(x * (-1.702f * 1.4426950408889634f));
+        return x * __builtin_amdgcn_rcpf(1.0f + e);
+    } else {
+        return x / (1.0f + expf(-1.702f * x));
+    }
 }
 
 // ------------------------------------------------------------------ preprocessing
@@ -933,11 +939,21 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 // and the exponentiated tile is already the A operand of P V (k-slot (g,e) of
 // step s = key 32s + 16(e>>2) + 4g + (e&3)); V is consumed through
 // ds_read_b64_tr_b16 so the same row-major image serves as the B operand.
+// Softmax runs in the exp2 domain with the 1/8 scale folded in (one fma + one v_exp
+// per score); only key tiles that hold a key >= S are masked, tiles entirely beyond S
+// are never computed.  The output tile is transposed through a wave-private LDS patch
+// so that each lane stores 16 contiguous bytes of a context row.
 // S <= S_PAD, S_PAD % 32 == 0; the whole score row of a query lives in registers.
-template <int S_PAD>
-__global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                        int S, int D, int H) {
+// (hipcc pitfall: assembling the bf16x8 B fragment element by element from the transposed
+//  read's v4i16 result miscompiled to a splat of element 0 — use the v4bf16 builtin and
+//  __builtin_shufflevector.)
+// S_CT > 0: the token count is a compile-time constant (launcher checks S == S_CT), so every
+// "does this key tile exist / straddle S" test folds away; S_CT == 0 keeps them at run time.
+template <int S_PAD, int S_CT>
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                           int S_rt, int D, int H) {
     constexpr int NKT = S_PAD / 16, NPV = S_PAD / 32;
+    const int S = S_CT > 0 ? S_CT : S_rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ks = smem;
     unsigned char* Vs = smem + S_PAD * 128;
@@ -946,63 +962,87 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     const int b = blockIdx.x / H, hh = blockIdx.x % H;
     const size_t ld = (size_t)3 * D;
     const bf16_t* base = qkv + (size_t)b * S * ld + hh * 64;
+    unsigned char* patch = smem + S_PAD * 256 + wave * 2048;  // 16 rows x 128 B, chunk ^= row & 7
 
-    for (int idx = tid; idx < S_PAD * 8; idx += 256) {
-        const int row = idx >> 3, c = idx & 7;
-        v4u kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-        if (row < S) {
-            kv = *reinterpret_cast<const v4u*>(base + (size_t)row * ld + D + c * 8);
-            vv = *reinterpret_cast<const v4u*>(base + (size_t)row * ld + 2 * D + c * 8);
+    // K and V go HBM -> LDS by LDS-DMA, 8 rows (1 KiB) per wave-instruction; the image is linear,
+    // the XOR swizzle is applied to the per-lane source chunk; rows >= S lie beyond the
+    // descriptor's num_records, so the hardware range check fills them with zeros.
+    {
+        const rsrc_t kvr = make_rsrc(base, (uint32_t)((size_t)S * ld * 2 - (size_t)hh * 128));
+        const int rr = lane >> 3, p = lane & 7;
+        const uint32_t voff = (uint32_t)rr * (uint32_t)(ld * 2) + 16u * (uint32_t)(p ^ rr);
+        for (int j = __builtin_amdgcn_readfirstlane(wave); j < S_PAD / 8; j += 4) {
+            const uint32_t so = (uint32_t)(8 * j) * (uint32_t)(ld * 2);
+            glds16_buf(kvr, voff, so + (uint32_t)D * 2u, Ks + j * 1024);
+            glds16_buf(kvr, voff, so + (uint32_t)D * 4u, Vs + j * 1024);
         }
-        const int off = row * 128 + ((c ^ (row & 7)) << 4);
-        *reinterpret_cast<v4u*>(Ks + off) = kv;
-        *reinterpret_cast<v4u*>(Vs + off) = vv;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
     const int nqt = (S + 15) / 16;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    const int nkt = (S + 15) / 16;                 // key tiles that hold at least one key
+    constexpr float C2 = 0.125f * 1.4426950408889634f;  // scale * log2(e)
+    // rotate the start so the wave that gets the extra query tile differs between co-resident workgroups
+    auto load_q = [&](bf16x8 (&q)[2], int qt) {
         const int qi = qt * 16 + l15;
         const int qc = qi < S ? qi : S - 1;
-        bf16x8 qf[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * ld + 32 * ks + 8 * g);
+        for (int ks = 0; ks < 2; ++ks) q[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * ld + 32 * ks + 8 * g);
+    };
+    bf16x8 qf[2], qn[2];
+    const int qt0 = (wave + blockIdx.x) & 3;
+    load_q(qn, qt0 < nqt ? qt0 : 0);
+    for (int qt = qt0; qt < nqt; qt += 4) {
+        qf[0] = qn[0]; qf[1] = qn[1];
+        load_q(qn, qt + 4 < nqt ? qt + 4 : qt);  // next tile's queries travel while this one computes
 
         v4f sc[NKT];
 #pragma unroll
         for (int T = 0; T < NKT; ++T) {
             sc[T] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+            if (T < nkt) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int row = 16 * T + l15;
-                const bf16x8 kf =
-                    *reinterpret_cast<const bf16x8*>(Ks + row * 128 + (((4 * ks + g) ^ (row & 7)) << 4));
-                sc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[T], 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int row = 16 * T + l15;
+                    const bf16x8 kf =
+                        *reinterpret_cast<const bf16x8*>(Ks + row * 128 + (((4 * ks + g) ^ (row & 7)) << 4));
+                    sc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[T], 0, 0, 0);
+                }
             }
         }
-        // sc[T][e] = (K Q^T)[key 16T + 4g + e][query l15]
+        // sc[T][e] = (K Q^T)[key 16T + 4g + e][query l15]; mask the tile that straddles S
         float mx = -INFINITY;
 #pragma unroll
-        for (int T = 0; T < NKT; ++T)
+        for (int T = 0; T < NKT; ++T) {
+            if (T < nkt) {
+                if (16 * T + 16 > S) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = 16 * T + 4 * g + e;
-                const float v = key < S ? sc[T][e] * 0.125f : -INFINITY;
-                sc[T][e] = v;
-                mx = fmaxf(mx, v);
+                    for (int e = 0; e < 4; ++e)
+                        if (16 * T + 4 * g + e >= S) sc[T][e] = -INFINITY;
+                }
+                mx = fmaxf(mx, fmaxf(fmaxf(sc[T][0], sc[T][1]), fmaxf(sc[T][2], sc[T][3])));
             }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mc = -mx * C2;
         float sum = 0.0f;
+        bf16x8 pa[NPV];
 #pragma unroll
-        for (int T = 0; T < NKT; ++T)
+        for (int s = 0; s < NPV; ++s) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float pw = __expf(sc[T][e] - mx);
-                sc[T][e] = pw;
-                sum += pw;
+            for (int half = 0; half < 2; ++half) {
+                const int T = 2 * s + half;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pw = 0.0f;
+                    if (T < nkt) pw = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[T][e], C2, mc));
+                    sum += pw;
+                    pa[s][4 * half + e] = (__bf16)pw;
+                }
             }
+        }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
@@ -1014,35 +1054,43 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
         const int tq = l15 >> 2, tp = l15 & 3;
 #pragma unroll
         for (int s = 0; s < NPV; ++s) {
-            bf16x8 pa;
+            if (2 * s < nkt) {
+                const int key0 = 32 * s + 4 * g + tq, key1 = key0 + 16;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                pa[e] = (__bf16)sc[2 * s][e];
-                pa[4 + e] = (__bf16)sc[2 * s + 1][e];
-            }
-            const int key0 = 32 * s + 4 * g + tq, key1 = key0 + 16;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const int c = 2 * dt + (tp >> 1), sub = (tp & 1) * 8;
-                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(Vs + key0 * 128 + ((c ^ (key0 & 7)) << 4) + sub));
-                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(Vs + key1 * 128 + ((c ^ (key1 & 7)) << 4) + sub));
-                const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vf, o[dt], 0, 0, 0);
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int c = 2 * dt + (tp >> 1), sub = (tp & 1) * 8;
+                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(Vs + key0 * 128 + ((c ^ (key0 & 7)) << 4) + sub));
+                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(Vs + key1 * 128 + ((c ^ (key1 & 7)) << 4) + sub));
+                    const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[s], vf, o[dt], 0, 0, 0);
+                }
             }
         }
-        // o[dt][e] = O[query 4g + e][d = 16 dt + l15]
+        // o[dt][e] = O[query 4g + e][d = 16 dt + l15]  ->  patch[query][d] (bf16), then 16-byte row stores
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float ie = __shfl(inv, 4 * g + e, 64);
-            const int qrow = qt * 16 + 4 * g + e;
-            if (qrow < S) {
-                bf16_t* dst = ctx + ((size_t)b * S + qrow) * D + hh * 64 + l15;
+            const int r = 4 * g + e;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) dst[16 * dt] = f2bf(o[dt][e] * ie);
+            for (int dt = 0; dt < 4; ++dt) {
+                const int col = 16 * dt + l15;  // bf16 column; 16-byte chunk = col >> 3
+                *reinterpret_cast<bf16_t*>(patch + r * 128 + ((((col >> 3) ^ (r & 7))) << 4) + (col & 7) * 2) =
+                    f2bf(o[dt][e] * ie);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = j * 8 + (lane >> 3), c = lane & 7;
+            const v4u d = *reinterpret_cast<const v4u*>(patch + r * 128 + ((c ^ (r & 7)) << 4));
+            const int qrow = qt * 16 + r;
+            if (qrow < S) *reinterpret_cast<v4u*>(ctx + ((size_t)b * S + qrow) * D + hh * 64 + c * 8) = d;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
