@@ -42,6 +42,13 @@ void ensure(void** p, size_t* have, size_t want, size_t elem) {
     *have = want;
 }
 
+// the handle's own stream, created on first use (an idle stream still takes one of the four
+// hardware queues HIP multiplexes streams onto)
+hipStream_t own_stream(mi_knn* t) {
+    if (!t->stream) HIP_CHECK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    return t->stream;
+}
+
 void grow(mi_knn* t, uint64_t want_rows) {
     if (want_rows <= t->cap) return;
     uint64_t ncap = std::max<uint64_t>(want_rows, t->cap + t->cap / 2);
@@ -51,7 +58,7 @@ void grow(mi_knn* t, uint64_t want_rows) {
     float* nt = nullptr;
     HIP_CHECK(hipMalloc((void**)&nt, ncap * t->dim * sizeof(float)));
     if (t->rows) {
-        HIP_CHECK(hipMemcpyAsync(nt, t->table, t->rows * t->dim * sizeof(float), hipMemcpyDeviceToDevice, t->stream));
+        HIP_CHECK(hipMemcpyAsync(nt, t->table, t->rows * t->dim * sizeof(float), hipMemcpyDeviceToDevice, own_stream(t)));
         HIP_CHECK(hipStreamSynchronize(t->stream));
     }
     if (t->table) HIP_CHECK(hipFree(t->table));
@@ -197,7 +204,6 @@ int mi_knn_create(uint32_t dim, int device, mi_knn** out) {
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         t->n_cu = prop.multiProcessorCount;
-        HIP_CHECK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void**)&t->d_q, (size_t)16 * dim * sizeof(float)));
         *out = t;
     });
@@ -244,6 +250,7 @@ int mi_knn_append(mi_knn* t, const float* rows, uint64_t n) {
         if (!rows) fail(MI_ERR_INVALID, "rows is null");
         std::lock_guard<std::mutex> l(t->mu);
         DeviceGuard g(t->device);
+        own_stream(t);
         grow(t, t->rows + n);
         HIP_CHECK(hipMemcpyAsync(t->table + t->rows * t->dim, rows, n * t->dim * sizeof(float), hipMemcpyHostToDevice,
                                  t->stream));
@@ -259,7 +266,7 @@ int mi_knn_append_device(mi_knn* t, const float* d_rows, uint64_t n, void* strea
         if (!d_rows) fail(MI_ERR_INVALID, "d_rows is null");
         std::lock_guard<std::mutex> l(t->mu);
         DeviceGuard g(t->device);
-        hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+        hipStream_t s = stream ? (hipStream_t)stream : own_stream(t);
         if (t->rows + n > t->cap) {  // growing reallocates: make the caller's stream wait for it
             HIP_CHECK(hipStreamSynchronize(s));
             grow(t, t->rows + n);
@@ -276,6 +283,7 @@ int mi_knn_append_synthetic(mi_knn* t, uint64_t seed, uint64_t first_row, uint64
         if (n == 0) return;
         std::lock_guard<std::mutex> l(t->mu);
         DeviceGuard g(t->device);
+        own_stream(t);
         grow(t, t->rows + n);
         const uint64_t key = [&] {  // synth.py: mix64(seed + GOLDEN)
             uint64_t z = seed + 0x9E3779B97F4A7C15ull;
@@ -302,6 +310,7 @@ int mi_knn_get_rows(mi_knn* t, uint64_t first, uint64_t n, float* out) {
                                       (unsigned long long)first, (unsigned long long)(first + n),
                                       (unsigned long long)t->rows);
         DeviceGuard g(t->device);
+        own_stream(t);
         HIP_CHECK(hipMemcpyAsync(out, t->table + first * t->dim, n * t->dim * sizeof(float), hipMemcpyDeviceToHost,
                                  t->stream));
         HIP_CHECK(hipStreamSynchronize(t->stream));
@@ -314,7 +323,7 @@ int mi_knn_search_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, u
         check_search_args(t, d_q, nq, k, d_idx, d_dist);
         std::lock_guard<std::mutex> l(t->mu);
         DeviceGuard g(t->device);
-        hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+        hipStream_t s = stream ? (hipStream_t)stream : own_stream(t);
         for (uint32_t u = 0; u < nq; ++u)
             search_one(t, d_q + (size_t)u * t->dim, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
     });
@@ -327,7 +336,7 @@ int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint3
         if (nq > 16) fail(MI_ERR_UNSUPPORTED, "batched search takes at most 16 queries (got %u)", nq);
         std::lock_guard<std::mutex> l(t->mu);
         DeviceGuard g(t->device);
-        hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+        hipStream_t s = stream ? (hipStream_t)stream : own_stream(t);
         uint32_t u = 0;
         while (u < nq) {
             const uint32_t left = nq - u;
@@ -345,6 +354,7 @@ int mi_knn_search(mi_knn* t, const float* q, uint32_t nq, uint32_t k, uint64_t* 
         if (nq == 0) return;
         std::lock_guard<std::mutex> l(t->mu);
         DeviceGuard g(t->device);
+        own_stream(t);
         ensure((void**)&t->d_idx, &t->idx_cap, k, sizeof(uint64_t));
         ensure((void**)&t->d_dist, &t->dist_cap, k, sizeof(float));
         for (uint32_t u = 0; u < nq; ++u) {

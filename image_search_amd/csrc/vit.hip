@@ -192,9 +192,17 @@ struct mi_clip {
     // workspace for `cap` images
     size_t cap = 0;
     std::vector<void*> ws;
-    float *d_in = nullptr, *d_patch = nullptr, *d_x = nullptr, *d_out = nullptr;
-    void *d_col = nullptr, *d_y = nullptr, *d_qkv = nullptr, *d_h = nullptr;
-    bf16_t* d_delta = nullptr;  // bf16 path: out_proj / fc2 output, added to x by the next LayerNorm
+    float *d_in = nullptr, *d_out = nullptr;
+    // activations: set 0 serves a whole chunk; set 1 exists so that two half-chunks can run as two
+    // independent streams (see forward()).
+    struct Act {
+        float *patch = nullptr, *x = nullptr;
+        void *col = nullptr, *y = nullptr, *qkv = nullptr, *h = nullptr;
+        bf16_t* delta = nullptr;  // bf16 path: out_proj / fc2 output, added to x by the next LayerNorm
+    } act[4];
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    int parts = 2;  // MI_CLIP_PARTS: sub-chunks run as independent streams
     int n_cu = 256;
     uint8_t* d_rgb = nullptr;
     hipStream_t stream = nullptr;
@@ -304,8 +312,14 @@ void load_weights(mi_clip* m, const char* path) {
 }
 
 
+hipStream_t own_stream(mi_clip* m) {
+    if (!m->stream) HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    return m->stream;
+}
+
 void ensure_workspace(mi_clip* m, size_t n) {
     if (n <= m->cap) return;
+    own_stream(m);
     for (void* p : m->ws) HIP_CHECK(hipFree(p));
     m->ws.clear();
     m->cap = 0;
@@ -320,13 +334,19 @@ void ensure_workspace(mi_clip* m, size_t n) {
     const size_t px = (size_t)m->image * m->image * 3;
     m->d_in = (float*)bytes(n * px * 4);
     m->d_rgb = (uint8_t*)bytes(n * px);
-    m->d_col = bytes(Pp * m->Kp * es);
-    m->d_patch = (float*)bytes(Pp * m->D * 4);
-    m->d_x = (float*)bytes(Mp * m->D * 4);
-    m->d_y = bytes(Mp * m->D * es);
-    m->d_qkv = bytes(Mp * 3 * m->D * es);
-    m->d_h = bytes(Mp * m->FF * es);
-    m->d_delta = (bf16_t*)bytes(Mp * m->D * 2);
+    for (int a = 0; a < 4; ++a) {
+        const size_t na = a == 0 ? n : (n + 1) / 2;
+        const size_t Ma = pad256(na * m->S), Pa = pad256(na * (m->S - 1));
+        if (na == 0) continue;
+        m->act[a].col = bytes(Pa * m->Kp * es);
+        m->act[a].patch = (float*)bytes(Pa * m->D * 4);
+        m->act[a].x = (float*)bytes(Ma * m->D * 4);
+        m->act[a].y = bytes(Ma * m->D * es);
+        m->act[a].qkv = bytes(Ma * 3 * m->D * es);
+        m->act[a].h = bytes(Ma * m->FF * es);
+        m->act[a].delta = (bf16_t*)bytes(Ma * m->D * 2);
+    }
+    (void)Mp; (void)Pp;
     m->d_out = (float*)bytes(n * m->E * 4);
     HIP_CHECK(hipStreamSynchronize(m->stream));
     m->cap = n;
@@ -410,10 +430,10 @@ void layer_norm(mi_clip* m, float* x, const bf16_t* delta, void* y, const float*
     HIP_CHECK(hipGetLastError());
 }
 
-void attention(mi_clip* m, size_t n, hipStream_t s) {
+void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s) {
     if (m->precision == MI_PRECISION_F32) {
         const unsigned blocks = (unsigned)(n * m->H * ((m->S + 63) / 64));
-        hipLaunchKernelGGL(attn_f32_kernel, dim3(blocks), dim3(64), 0, s, (const float*)m->d_qkv, (float*)m->d_y, m->S, m->D, m->H);
+        hipLaunchKernelGGL(attn_f32_kernel, dim3(blocks), dim3(64), 0, s, (const float*)qkv, (float*)ctx, m->S, m->D, m->H);
     } else {
         const unsigned blocks = (unsigned)(n * m->H);
         const int sp = (m->S + 31) / 32 * 32;
@@ -421,7 +441,7 @@ void attention(mi_clip* m, size_t n, hipStream_t s) {
     {                                                                                                                \
         static bool done = false;                                                                                    \
         if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)attn_bf16_kernel<SP, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, SP * 256 + 8192)); done = true; } \
-        hipLaunchKernelGGL((attn_bf16_kernel<SP, SC>), dim3(blocks), dim3(256), SP * 256 + 8192, s, (const bf16_t*)m->d_qkv, (bf16_t*)m->d_y, m->S, m->D, m->H); \
+        hipLaunchKernelGGL((attn_bf16_kernel<SP, SC>), dim3(blocks), dim3(256), SP * 256 + 8192, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H); \
     }
         if (m->S == 257) MI_ATTN(288, 257)       // ViT-L/14, ViT-H/14 @224
         else if (m->S == 197) MI_ATTN(224, 197)  // ViT-B/16 @224
@@ -436,56 +456,91 @@ void attention(mi_clip* m, size_t n, hipStream_t s) {
     HIP_CHECK(hipGetLastError());
 }
 
-// the whole tower on n <= cap device-resident images
-void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t s) {
+// the whole tower on n <= cap device-resident images.
+// bf16, n >= 32: the chunk is cut into two halves that run as two independent streams with their
+// own activation sets, launches interleaved layer by layer.  The persistent GEMM of one half
+// owns every CU's LDS while it runs, but the other half's LayerNorms (no LDS, 60 VGPRs) share
+// the CUs with it, and whichever kernel of the other half is next fills the CUs that fall idle
+// in a GEMM's last, partial round of tiles (257 row-tiles never divide by 256 CUs).
+void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t s0) {
     const int D = m->D, S = m->S, FF = m->FF;
-    const size_t M = n * S, P = n * (S - 1);
-    // patch embedding: gather -> GEMM [P,Kp] x [D,Kp]^T -> f32
-    {
-        const size_t total = P * m->Kp;
+    const size_t px = (size_t)m->image * m->image * 3;
+    const bool deferred = m->precision == MI_PRECISION_BF16;
+    const int parts = (deferred && m->parts > 1 && n >= 32) ? m->parts : 1;
+    struct Part { size_t n, M, P; const float* img; float* out; hipStream_t s; mi_clip::Act* a; const bf16_t* pending; } pt[4];
+    for (size_t p = 0, first = 0; p < (size_t)parts; ++p) {
+        const size_t np = n / parts + (p < n % parts ? 1 : 0);
+        pt[p] = {np, np * S, np * (S - 1), d_img + first * px, d_out + first * m->E, p == 0 ? s0 : m->aux[p - 1], &m->act[p], nullptr};
+        first += np;
+    }
+    if (parts > 1) {
+        for (int p = 1; p < parts; ++p)
+            if (!m->aux[p - 1]) {
+                HIP_CHECK(hipStreamCreateWithFlags(&m->aux[p - 1], hipStreamNonBlocking));
+                pt[p].s = m->aux[p - 1];
+            }
+        HIP_CHECK(hipEventRecord(m->ev_fork, s0));
+        for (int p = 1; p < parts; ++p) HIP_CHECK(hipStreamWaitEvent(m->aux[p - 1], m->ev_fork, 0));
+    }
+    for (int p = 0; p < parts; ++p) {
+        Part& q = pt[p];
+        // patch embedding: gather -> GEMM [P,Kp] x [D,Kp]^T -> f32
+        const size_t total = q.P * m->Kp;
         const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65535 * 4);
         if (m->precision == MI_PRECISION_F32)
-            hipLaunchKernelGGL((im2col_kernel<float>), dim3(blocks), dim3(256), 0, s, d_img, (float*)m->d_col, (int)n, m->grid, m->patch, m->image, m->Kp);
+            hipLaunchKernelGGL((im2col_kernel<float>), dim3(blocks), dim3(256), 0, q.s, q.img, (float*)q.a->col, (int)q.n, m->grid, m->patch, m->image, m->Kp);
         else
-            hipLaunchKernelGGL((im2col_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, d_img, (bf16_t*)m->d_col, (int)n, m->grid, m->patch, m->image, m->Kp);
+            hipLaunchKernelGGL((im2col_kernel<bf16_t>), dim3(blocks), dim3(256), 0, q.s, q.img, (bf16_t*)q.a->col, (int)q.n, m->grid, m->patch, m->image, m->Kp);
         HIP_CHECK(hipGetLastError());
-        gemm<EPI_STORE_F32>(m, m->d_col, m->wpatch, nullptr, m->d_patch, P, D, m->Kp, D, s);
-    }
-    {
-        const unsigned blocks = (unsigned)((M + 3) / 4);
-        MI_LN_DISPATCH(D, hipLaunchKernelGGL((embed_ln_kernel<VEC, NT>), dim3(blocks), dim3(256), 0, s, m->d_patch, m->cls, m->pos, m->d_x, m->pre_w, m->pre_b, (int)M, S, m->eps));
+        gemm<EPI_STORE_F32>(m, q.a->col, m->wpatch, nullptr, q.a->patch, q.P, D, m->Kp, D, q.s);
+        const unsigned lb = (unsigned)((q.M + 3) / 4);
+        MI_LN_DISPATCH(D, hipLaunchKernelGGL((embed_ln_kernel<VEC, NT>), dim3(lb), dim3(256), 0, q.s, q.a->patch, m->cls, m->pos, q.a->x, m->pre_w, m->pre_b, (int)q.M, S, m->eps));
         HIP_CHECK(hipGetLastError());
     }
     // fp32 path: the residual add is the GEMM epilogue (x += acc + bias, fp32 read-modify-write).
     // bf16 path: out_proj / fc2 store a bf16 `delta` (a pure, asynchronous store from the persistent
     // GEMM) and the LayerNorm that follows — which streams x anyway — does x += delta.
-    const bool deferred = m->precision == MI_PRECISION_BF16;
-    const bf16_t* pending = nullptr;
     for (const Layer& ly : m->layers) {
-        layer_norm(m, m->d_x, pending, m->d_y, ly.ln1w, ly.ln1b, M, s);
-        gemm<EPI_BIAS>(m, m->d_y, ly.wqkv, ly.bqkv, m->d_qkv, M, 3 * D, D, 3 * D, s);
-        attention(m, n, s);
-        if (deferred) {
-            gemm<EPI_BIAS>(m, m->d_y, ly.wo, ly.bo, m->d_delta, M, D, D, D, s);
-            layer_norm(m, m->d_x, m->d_delta, m->d_y, ly.ln2w, ly.ln2b, M, s);
-            gemm<EPI_BIAS_QGELU>(m, m->d_y, ly.w1, ly.b1, m->d_h, M, FF, D, FF, s);
-            gemm<EPI_BIAS>(m, m->d_h, ly.w2, ly.b2, m->d_delta, M, D, FF, D, s);
-            pending = m->d_delta;
-        } else {
-            gemm<EPI_BIAS_RESID>(m, m->d_y, ly.wo, ly.bo, m->d_x, M, D, D, D, s);
-            layer_norm(m, m->d_x, nullptr, m->d_y, ly.ln2w, ly.ln2b, M, s);
-            gemm<EPI_BIAS_QGELU>(m, m->d_y, ly.w1, ly.b1, m->d_h, M, FF, D, FF, s);
-            gemm<EPI_BIAS_RESID>(m, m->d_h, ly.w2, ly.b2, m->d_x, M, D, FF, D, s);
+        for (int p = 0; p < parts; ++p) {
+            Part& q = pt[p];
+            layer_norm(m, q.a->x, q.pending, q.a->y, ly.ln1w, ly.ln1b, q.M, q.s);
+            gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, D, 3 * D, q.s);
+            attention(m, q.a->qkv, q.a->y, q.n, q.s);
+        }
+        for (int p = 0; p < parts; ++p) {
+            Part& q = pt[p];
+            if (deferred) {
+                gemm<EPI_BIAS>(m, q.a->y, ly.wo, ly.bo, q.a->delta, q.M, D, D, D, q.s);
+                layer_norm(m, q.a->x, q.a->delta, q.a->y, ly.ln2w, ly.ln2b, q.M, q.s);
+                gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, D, FF, q.s);
+                gemm<EPI_BIAS>(m, q.a->h, ly.w2, ly.b2, q.a->delta, q.M, D, FF, D, q.s);
+                q.pending = q.a->delta;
+            } else {
+                gemm<EPI_BIAS_RESID>(m, q.a->y, ly.wo, ly.bo, q.a->x, q.M, D, D, D, q.s);
+                layer_norm(m, q.a->x, nullptr, q.a->y, ly.ln2w, ly.ln2b, q.M, q.s);
+                gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, D, FF, q.s);
+                gemm<EPI_BIAS_RESID>(m, q.a->h, ly.w2, ly.b2, q.a->x, q.M, D, FF, D, q.s);
+            }
         }
     }
-    MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)n), dim3(256), 0, s, m->d_x, pending, m->post_w, m->post_b, m->proj, d_out, S, m->E, m->eps));
-    HIP_CHECK(hipGetLastError());
+    for (int p = 0; p < parts; ++p) {
+        Part& q = pt[p];
+        MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)q.n), dim3(256), 0, q.s, q.a->x, q.pending, m->post_w, m->post_b, m->proj, q.out, S, m->E, m->eps));
+        HIP_CHECK(hipGetLastError());
+    }
+    for (int p = 1; p < parts; ++p) {
+        HIP_CHECK(hipEventRecord(m->ev_join[p - 1], m->aux[p - 1]));
+        HIP_CHECK(hipStreamWaitEvent(s0, m->ev_join[p - 1], 0));
+    }
 }
 
 void free_model(mi_clip* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    for (auto& a : m->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    for (auto& e : m->ev_join) if (e) (void)hipEventDestroy(e);
     for (void* p : m->allocs) (void)hipFree(p);
     for (void* p : m->ws) (void)hipFree(p);
     delete m;
@@ -508,7 +563,11 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         m->device = device;
         m->precision = precision;
         if (const char* e = std::getenv("MI_CLIP_MAX_BATCH")) m->max_batch = std::max(1, std::atoi(e));
-        HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+        // aux streams are created on first use: HIP multiplexes streams onto 4 hardware queues
+        // (GPU_MAX_HW_QUEUES), and two streams that share a queue do not overlap
+        HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+        for (auto& e : m->ev_join) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (const char* e = std::getenv("MI_CLIP_PARTS")) m->parts = std::min(4, std::max(1, std::atoi(e)));
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         m->n_cu = prop.multiProcessorCount;
@@ -536,7 +595,7 @@ int mi_clip_embed_device(mi_clip* m, const float* d_nchw, size_t n, float* d_out
         if (!d_nchw || !d_out) fail(MI_ERR_INVALID, "null buffer");
         std::lock_guard<std::mutex> l(m->mu);
         DeviceGuard g(m->device);
-        hipStream_t s = stream ? (hipStream_t)stream : m->stream;
+        hipStream_t s = stream ? (hipStream_t)stream : own_stream(m);
         const size_t px = (size_t)m->image * m->image * 3;
         const size_t chunk = std::min(n, m->max_batch);
         if (chunk > m->cap) { HIP_CHECK(hipStreamSynchronize(s)); ensure_workspace(m, chunk); }
@@ -651,11 +710,11 @@ int mi_op_attention(int device, int precision, const float* qkv, float* ctx, siz
         mi_clip m;
         m.precision = precision; m.S = s_tok; m.D = d; m.H = heads;
         const size_t rows = n_img * s_tok;
-        m.d_qkv = sc.up(precision, qkv, rows, 3 * (size_t)d, pad256(rows));
-        m.d_y = sc.bytes(pad256(rows) * d * 4);
-        attention(&m, n_img, nullptr);
+        void* dq = sc.up(precision, qkv, rows, 3 * (size_t)d, pad256(rows));
+        void* dc = sc.bytes(pad256(rows) * d * 4);
+        attention(&m, dq, dc, n_img, nullptr);
         HIP_CHECK(hipDeviceSynchronize());
-        sc.down(precision, m.d_y, ctx, rows * d);
+        sc.down(precision, dc, ctx, rows * d);
     });
 }
 
