@@ -394,9 +394,12 @@ void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out
             static bool done = false;
             if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); done = true; }
             const int n_tiles = (int)((Mp / 256) * (N / 256));
-            const int grid = std::min(n_tiles, m->n_cu);
+            const int grid = std::min(n_tiles * 4, m->n_cu);
+            // a short last round (<= a quarter of the CUs busy) is cut into quadrant tasks
+            const int left = n_tiles % grid;
+            const int n_full = (left > 0 && left * 4 <= grid) ? n_tiles - left : n_tiles;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, (int)Mp, N,
-                               K, ldo, n_tiles);
+                               K, ldo, n_tiles, n_full);
             HIP_CHECK(hipGetLastError());
             return;
         }
@@ -689,11 +692,20 @@ int mi_op_linear(int device, int precision, int epilogue, const float* x, const 
         float* db = bias ? (float*)sc.up(MI_PRECISION_F32, bias, 1, n, 1) : nullptr;
         const bool f32_out = epilogue == EPI_STORE_F32 || epilogue == EPI_BIAS_RESID;
         void* dout = f32_out ? sc.up(MI_PRECISION_F32, out, m_rows, n, mp) : sc.bytes(mp * n * 4);
+        // same dispatcher as the tower (persistent 256x256 kernel when the shape allows);
+        // MI_OP_GRID overrides the CU count so that small test shapes exercise several tiles
+        // per workgroup and the split last round
+        mi_clip mm;
+        mm.precision = precision;
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        mm.n_cu = prop.multiProcessorCount;
+        if (const char* e = std::getenv("MI_OP_GRID")) mm.n_cu = std::max(1, std::atoi(e));
         switch (epilogue) {
-            case EPI_STORE_F32: gemm_p<EPI_STORE_F32>(precision, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;
-            case EPI_BIAS: gemm_p<EPI_BIAS>(precision, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;
-            case EPI_BIAS_QGELU: gemm_p<EPI_BIAS_QGELU>(precision, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;
-            case EPI_BIAS_RESID: gemm_p<EPI_BIAS_RESID>(precision, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;
+            case EPI_STORE_F32: gemm<EPI_STORE_F32>(&mm, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;
+            case EPI_BIAS: gemm<EPI_BIAS>(&mm, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;
+            case EPI_BIAS_QGELU: gemm<EPI_BIAS_QGELU>(&mm, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;
+            case EPI_BIAS_RESID: gemm<EPI_BIAS_RESID>(&mm, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;
             default: fail(MI_ERR_INVALID, "epilogue %d", epilogue);
         }
         HIP_CHECK(hipDeviceSynchronize());

@@ -704,7 +704,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
                                                                    const bf16_t* __restrict__ W,
                                                                    const float* __restrict__ bias,
                                                                    void* __restrict__ out, int M, int N, int K,
-                                                                   int ldo, int n_tiles) {
+                                                                   int ldo, int n_tiles, int n_full) {
     static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU, "the persistent form stores bf16 with bias");
     static_assert(sizeof(TO) == 2, "bf16 output");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 128 KiB staging + 18 KiB patches + 2 KiB bias
@@ -713,8 +713,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
     const int wm = wave >> 2, wn = wave & 3, g = lane >> 4, l15 = lane & 15;
     const int nt = N / 256;
     const int G = gridDim.x;
-    int tile = (int)xcd_remap(blockIdx.x, G);
-    if (tile >= n_tiles) return;
+    const int lb = (int)xcd_remap(blockIdx.x, G);
+    int tile = lb;
 
     const uint32_t Kb = (uint32_t)K * 2;
     const rsrc_t xr = make_rsrc(X, (uint32_t)M * Kb);
@@ -781,21 +781,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
     const int nk = K / 64;
     int b = 0, kt = 0;
     uint32_t xs = (uint32_t)(tile / nt) * 256u * Kb, ws = (uint32_t)(tile % nt) * 256u * Kb;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[a][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    if (tile < n_full) {
     stage_bias(tile);  // oldest op of the stream
 #pragma unroll
     for (int i = 0; i < 4; ++i) stage_half(0, xs, ws, 0, i);
     bool after_epilogue = false;
     // per-lane part of the output offset: row wm*128 + (lane>>3), column wn*64 + 8*(lane&7)
     const uint32_t o_lane = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[a][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
 
     for (;;) {
         const bool last_kt = (kt == nk - 1);
         const int next = tile + G;
-        const bool has_next = next < n_tiles;
+        const bool has_next = next < n_full;
         // what the four phases of this K tile stage: the next K tile of this tile, or K tile 0 of the next
         const uint32_t s_x = last_kt ? (uint32_t)(next / nt) * 256u * Kb : xs;
         const uint32_t s_w = last_kt ? (uint32_t)(next % nt) * 256u * Kb : ws;
@@ -859,6 +860,63 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
         kt = 0;
         after_epilogue = true;
         stage_bias(tile);  // one more counted op between the stores and the next K tile
+    }
+    }  // full tiles
+
+    // ---- the last, partial round: tiles [n_full, n_tiles) are cut into four quadrant tasks each
+    // (64 rows per wave-row x 32 columns per wave-column = quadrant (mh, nh) of the tile), so that
+    // up to 4x more CUs share it.  A task is the (0,0) quadrant of a virtual tile whose X / W rows
+    // start 64*mh / 32*nh rows further: only XH0 / WH0 are staged (2 K tiles ahead, both buffers).
+    const int n_tasks = (n_tiles - n_full) * 4;
+    for (int task = lb; task < n_tasks; task += G) {
+        const int t = n_full + (task >> 2), mh = (task >> 1) & 1, nh = task & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint32_t txs = (uint32_t)(t / nt) * 256u * Kb + 64u * mh * Kb, tws = (uint32_t)(t % nt) * 256u * Kb + 32u * nh * Kb;
+        stage_bias(t);
+        stage_half(0, txs, tws, 0, 0); stage_half(0, txs, tws, 0, 1);
+        if (nk > 1) { stage_half(1, txs, tws, 1, 0); stage_half(1, txs, tws, 1, 1); }
+        for (int kq = 0; kq < nk; ++kq) {
+            if (kq + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned char* base = smem + (kq & 1) * 65536;
+            load_x(base, 0); load_w(base, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave has its fragments: the buffer may be refilled
+            if (kq + 2 < nk) { stage_half(kq & 1, txs, tws, kq + 2, 0); stage_half(kq & 1, txs, tws, kq + 2, 1); }
+            MI_QUADRANT(0, 0)
+        }
+        // epilogue of the 64 x 32 quadrant of this wave: 4 m-tiles x 2 n-tiles, 64-byte row pieces
+        __builtin_amdgcn_sched_barrier(0);
+        v4f bq[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bq[ni] = *reinterpret_cast<const v4f*>(bias_lds + (32 * nh + ni * 16 + 4 * g) * 4);
+        unsigned char* patch = smem + 131072 + wave * 2304;
+        const uint32_t q_tile = ((uint32_t)(t / nt) * 256u * (uint32_t)ldo + (uint32_t)((t % nt) * 256)) * 2u;
+        const uint32_t q_lane = ((uint32_t)(wm * 128 + 64 * mh + (lane >> 2)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 32 * nh + 8 * (lane & 3))) * 2u;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                v4f v = acc[ni][mi] + bq[ni];
+                acc[ni][mi] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                if constexpr (EPI == EPI_BIAS_QGELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = quick_gelu<true>(v[c]);
+                }
+                v2u pk;
+                pk.x = pack2bf(v[0], v[1]);
+                pk.y = pack2bf(v[2], v[3]);
+                *reinterpret_cast<v2u*>(patch + l15 * 144 + (ni * 16 + 4 * g) * 2) = pk;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const v4u d = *reinterpret_cast<const v4u*>(patch + (lane >> 2) * 144 + (lane & 3) * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(d, orr, q_lane, q_tile + (uint32_t)(mi * 16) * (uint32_t)ldo * 2u, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #undef MI_QUADRANT
 #undef MI_SYNC

@@ -81,6 +81,27 @@ def test_linear_epilogues(built, prec, tol, shape):
     assert np.abs(ops.linear(x, w, b, ops.EPI_BIAS_QGELU, prec) - ref / (1 + np.exp(-1.702 * ref))).max() <= tol * scale
 
 
+@pytest.mark.parametrize("grid", ["8", "3", "64"])
+def test_persistent_gemm_rounds_and_split_tail(built, monkeypatch, grid):
+    """bf16 persistent 256x256 kernel: several tiles per workgroup, the counted store/LDS-DMA
+    queue across tile boundaries, and the quadrant tasks of a short last round — exact on
+    small integers, so any stale tile or misplaced store shows."""
+    monkeypatch.setenv("MI_OP_GRID", grid)
+    rng = np.random.default_rng(7)
+    for (m, n, k) in ((2304, 512, 256), (2304, 512, 128), (700, 1024, 320), (256, 256, 64 * 9)):
+        x = rng.integers(-2, 3, (m, k)).astype(np.float32)
+        w = rng.integers(-1, 2, (n, k)).astype(np.float32)
+        b = rng.integers(-3, 4, n).astype(np.float32)
+        ref = x @ w.T + b
+        assert np.abs(ref).max() <= 256  # exactly representable in bf16
+        assert np.array_equal(ops.linear(x, w, b, ops.EPI_BIAS, PRECISION_BF16), ref), (m, n, k)
+    x = rng.standard_normal((2304, 256)).astype(np.float32); w = (rng.standard_normal((512, 256)) / 16).astype(np.float32)
+    b = rng.standard_normal(512).astype(np.float32)
+    ref = bf16_round(x).astype(np.float64) @ bf16_round(w).astype(np.float64).T + b
+    got = ops.linear(x, w, b, ops.EPI_BIAS_QGELU, PRECISION_BF16)
+    assert np.abs(got - ref / (1 + np.exp(-1.702 * ref))).max() <= 1.2e-2 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("prec,tol", [(PRECISION_F32, 5e-6), (PRECISION_BF16, 6e-3)])
 @pytest.mark.parametrize("S", [17, 50, 197, 257])
 def test_attention(built, prec, tol, S):

@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
         auto k256 = [&] { hipLaunchKernelGGL((gemm_bf16_256_kernel<EPI_BIAS, bf16_t>), dim3((M / 256) * (s.N / 256)), dim3(512), 131072, 0, X, W, bias, (void*)O2, s.N, s.K, s.N); };
         auto k256p = [&] { hipLaunchKernelGGL((gemm_bf16_256p_kernel<EPI_BIAS, bf16_t>), dim3((M / 256) * (s.N / 256)), dim3(512), 131072, 0, X, W, bias, (void*)O2, s.N, s.K, s.N); };
         const int n_tiles = (int)((M / 256) * (s.N / 256));
-        auto kper = [&] { hipLaunchKernelGGL((gemm_bf16_persist_kernel<EPI_BIAS, bf16_t>), dim3(256), dim3(512), 151552, 0, X, W, bias, (void*)O2, (int)M, s.N, s.K, s.N, n_tiles); };
+        auto kper = [&] { hipLaunchKernelGGL((gemm_bf16_persist_kernel<EPI_BIAS, bf16_t>), dim3(256), dim3(512), 151552, 0, X, W, bias, (void*)O2, (int)M, s.N, s.K, s.N, n_tiles, n_tiles - ((n_tiles % 256) * 4 <= 256 ? n_tiles % 256 : 0)); };
         float t1 = time_ms(k128, 10), t2 = time_ms(k256, 10), t3 = time_ms(k256p, 10);
         CK(hipMemset(O2, 0, M * s.N * 2));
         float t4 = time_ms(kper, 10);
