@@ -1,0 +1,110 @@
+// image_search.hpp — C++ host-side mirror of the reference's interface for the hot path, on top of
+// the C ABI (include/mi355clip.h).  The reference is Rust (no toolchain in this image), so the
+// compiled-language host layer is C++: same names, argument meaning and error behaviour as
+//   clip::clip_vit_large_patch14::Model::{from_file, forward}   clip/src/lib.rs:2-7, server/src/clip.rs:46-48,:118
+//   average_slices                                              server/src/search.rs:127-150
+//   image_prepare_resnet (arithmetic)                           server/src/clip.rs:158-172
+//   the `embedding <|K|> $reference` statement                  server/src/search.rs:70-86
+// Where the reference panics (assert!/unwrap) this throws std::runtime_error with the same message.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/mi355clip.h"
+
+namespace image_search {
+
+inline void check(int rc) {
+    if (rc != MI_OK) throw std::runtime_error(std::string("mi355clip: ") + mi_last_error());
+}
+
+// fn average_slices(vectors: &Vec<&Vec<f32>>) -> Vec<f32>
+inline std::vector<float> average_slices(const std::vector<const std::vector<float>*>& vectors) {
+    if (vectors.empty()) throw std::runtime_error("Input must not be empty");
+    const size_t len = vectors[0]->size();
+    std::vector<const float*> ptrs;
+    for (auto v : vectors) {
+        if (v->size() != len) throw std::runtime_error("All vectors must have the same length");
+        ptrs.push_back(v->data());
+    }
+    std::vector<float> out(len);
+    check(mi_average_slices(ptrs.data(), ptrs.size(), len, out.data()));
+    return out;
+}
+
+// the extension allow-list of the ingest walk (server/src/clip.rs:60-66, test_matches :181-233)
+inline bool is_image_path(const std::string& path) {
+    const size_t slash = path.find_last_of("/\\");
+    const std::string name = slash == std::string::npos ? path : path.substr(slash + 1);
+    const size_t dot = name.rfind('.');
+    if (dot == std::string::npos || dot == 0) return false;
+    std::string ext = name.substr(dot + 1);
+    for (auto& c : ext) c = (char)std::tolower((unsigned char)c);
+    for (const char* e : {"jpg", "jpeg", "png", "gif", "bmp", "webp", "tiff"})
+        if (ext == e) return true;
+    return false;
+}
+
+// fn image_prepare_resnet(img) -> Vec<f32>, minus the resize: RGB8 HWC (224x224) -> CHW f32
+inline std::vector<float> image_prepare_resnet(const std::vector<uint8_t>& rgb8, uint32_t h = 224, uint32_t w = 224) {
+    if (rgb8.size() != (size_t)h * w * 3) throw std::runtime_error("rgb8 buffer is not h*w*3 bytes");
+    std::vector<float> out((size_t)h * w * 3);
+    check(mi_preprocess_rgb8(rgb8.data(), 1, h, w, out.data()));
+    return out;
+}
+
+namespace clip_vit_large_patch14 {
+class Model {
+    mi_clip* h_ = nullptr;
+    uint32_t info_[8] = {0};
+    explicit Model(mi_clip* h) : h_(h) { check(mi_clip_info(h_, info_)); }
+
+   public:
+    static Model from_file(const std::string& path, int device, int precision = MI_PRECISION_BF16) {
+        mi_clip* h = nullptr;
+        check(mi_clip_load(path.c_str(), device, precision, &h));
+        return Model(h);
+    }
+    Model(Model&& o) noexcept { *this = std::move(o); }
+    Model& operator=(Model&& o) noexcept { std::swap(h_, o.h_); std::swap(info_, o.info_); return *this; }
+    Model(const Model&) = delete;
+    ~Model() { mi_clip_free(h_); }
+    uint32_t image() const { return info_[0]; }
+    uint32_t proj() const { return info_[7]; }
+    // [n,3,H,W] f32 NCHW -> [n,proj] f32, flat (what `output.to_data()` + cast gives, clip.rs:120-124)
+    std::vector<float> forward(const std::vector<float>& nchw, size_t n) const {
+        if (nchw.size() != n * 3 * (size_t)image() * image()) throw std::runtime_error("input is not [n,3,H,W]");
+        std::vector<float> out(n * proj());
+        check(mi_clip_embed(h_, nchw.data(), n, out.data()));
+        return out;
+    }
+};
+}  // namespace clip_vit_large_patch14
+
+// table `image` + index `mt_pts` (server/src/clip.rs:135-143) as one HBM-resident shard
+class EmbeddingTable {
+    mi_knn* h_ = nullptr;
+    uint32_t dim_;
+
+   public:
+    explicit EmbeddingTable(uint32_t dim = 768, int device = 0, uint64_t base = 0) : dim_(dim) {
+        check(mi_knn_create(dim, device, &h_));
+        check(mi_knn_set_base(h_, base));
+    }
+    EmbeddingTable(const EmbeddingTable&) = delete;
+    ~EmbeddingTable() { mi_knn_free(h_); }
+    void insert(const std::vector<float>& rows) { check(mi_knn_append(h_, rows.data(), rows.size() / dim_)); }
+    uint64_t size() const { uint64_t n = 0; check(mi_knn_size(h_, &n)); return n; }
+    // `WHERE embedding <|k|> $reference`: ids and cosine distances, ascending
+    std::pair<std::vector<uint64_t>, std::vector<float>> knn(const std::vector<float>& reference, uint32_t k = 1000) const {
+        std::vector<uint64_t> idx(k);
+        std::vector<float> dist(k);
+        check(mi_knn_search(h_, reference.data(), 1, k, idx.data(), dist.data()));
+        return {idx, dist};
+    }
+};
+
+}  // namespace image_search

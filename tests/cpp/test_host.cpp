@@ -1,0 +1,60 @@
+// The reference's own unit tests, restated in C++ against the drop-in (no GPU needed), plus — when
+// run with the argument "gpu" — a small end-to-end use of the C++ mirror on device 0.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../image_search_amd/host/image_search.hpp"
+
+using namespace image_search;
+#define EXPECT(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    {   // server/src/search.rs:156-161  tes_average_vector
+        std::vector<float> a{1.0f, 2.0f, 4.0f, 4.0f, 10.0f}, b{1.0f, 1.0f, 2.0f, 4.0f, 0.0f};
+        auto r = average_slices({&a, &b});
+        EXPECT((r == std::vector<float>{1.0f, 1.5f, 3.0f, 4.0f, 5.0f}));
+        bool threw = false;
+        try { average_slices({}); } catch (const std::runtime_error& e) { threw = std::string(e.what()) == "Input must not be empty"; }
+        EXPECT(threw);
+        std::vector<float> c{1.0f};
+        threw = false;
+        try { average_slices({&a, &c}); } catch (const std::runtime_error&) { threw = true; }
+        EXPECT(threw);
+    }
+    {   // server/src/clip.rs:181-233  test_matches
+        EXPECT(!is_image_path("file.txt"));
+        EXPECT(is_image_path("file.jpg"));
+        EXPECT(is_image_path("file.png"));
+        EXPECT(!is_image_path("file.mp4"));
+        EXPECT(!is_image_path("file"));
+    }
+    {   // image_prepare_resnet arithmetic, server/src/clip.rs:164-172
+        std::vector<uint8_t> px(224 * 224 * 3);
+        for (size_t i = 0; i < px.size(); ++i) px[i] = (uint8_t)(i * 7 + 3);
+        auto chw = image_prepare_resnet(px);
+        const size_t i = 1234;
+        EXPECT(chw[i] == ((float)px[i * 3] / 255.0f - 0.485f) / 0.229f);
+        EXPECT(chw[224 * 224 + i] == ((float)px[i * 3 + 1] / 255.0f - 0.456f) / 0.224f);
+        EXPECT(chw[2 * 224 * 224 + i] == ((float)px[i * 3 + 2] / 255.0f - 0.406f) / 0.225f);
+    }
+    if (argc > 1 && std::strcmp(argv[1], "gpu") == 0) {
+        EmbeddingTable t(768, 0);
+        std::vector<float> rows(5 * 768, 0.0f);
+        for (int r = 0; r < 5; ++r) { rows[r * 768 + r] = 1.0f; rows[r * 768 + 5] = 0.1f * r; }
+        t.insert(rows);
+        EXPECT(t.size() == 5);
+        std::vector<float> q(768, 0.0f); q[3] = 1.0f;
+        auto res = t.knn(q, 7);
+        EXPECT(res.first[0] == 3);
+        EXPECT(res.first[5] == MI_KNN_NO_ID && std::isinf(res.second[6]));
+        for (int i = 1; i < 5; ++i) EXPECT(res.second[i] >= res.second[i - 1]);
+    } else if (mi_device_count() == 0) {
+        bool threw = false;
+        try { EmbeddingTable t(768, 0); } catch (const std::runtime_error& e) { threw = std::strstr(e.what(), "no CPU fallback") != nullptr; }
+        EXPECT(threw);  // loud failure, no fallback
+    }
+    std::printf("ok\n");
+    return 0;
+}

@@ -133,3 +133,28 @@ def test_safetensors_writer_roundtrip(tmp_path):
     back = load_file(p)
     assert set(back) == set(w)
     assert all(np.array_equal(back[k], w[k]) for k in w)
+
+
+def _build_cpp_host_test(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "test_host_cpp")
+    lib_dir = os.path.join(ROOT, "image_search_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "test_host.cpp"), "-o", exe,
+                           "-L" + lib_dir, "-lmi355clip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_host_mirror_reference_unit_tests(mi, tmp_path):
+    """image_search_amd/host/image_search.hpp: the reference's tes_average_vector / test_matches in C++."""
+    import subprocess
+    exe = _build_cpp_host_test(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_on_gpu(mi, tmp_path):
+    import subprocess
+    exe = _build_cpp_host_test(tmp_path)
+    out = subprocess.run([exe, "gpu"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
