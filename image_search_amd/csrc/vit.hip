@@ -390,9 +390,17 @@ void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) {
         if (big) {
             constexpr int LDS = 131072 + 18432 + 2048;
-            auto kern = gemm_bf16_persist_kernel<EPI, bf16_t>;
+            // Default: the plain persistent form (186 VGPRs: the other half-chunk's LayerNorm waves still
+            // fit beside it; 45.7 vs 47.2 ms per 256 images).  MI_GEMM_V=2 selects the fragment-prefetch
+            // form (254 VGPRs; 1-2 % faster alone, K/64 must be even).
+            static const bool v2 = std::getenv("MI_GEMM_V") && std::atoi(std::getenv("MI_GEMM_V")) == 2;
+            auto kern = (v2 && (K / 64) % 2 == 0) ? gemm_bf16_persist2_kernel<EPI, bf16_t> : gemm_bf16_persist_kernel<EPI, bf16_t>;
             static bool done = false;
-            if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); done = true; }
+            if (!done) {
+                HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_persist2_kernel<EPI, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<EPI, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                done = true;
+            }
             const int n_tiles = (int)((Mp / 256) * (N / 256));
             const int grid = std::min(n_tiles * 4, m->n_cu);
             // a short last round (<= a quarter of the CUs busy) is cut into quadrant tasks
