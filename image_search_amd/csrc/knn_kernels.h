@@ -329,7 +329,9 @@ __global__ __launch_bounds__(256) void knn_scan_batched_kernel(const float* __re
                 float d0 = 0, d1 = 0, d2 = 0, d3 = 0;
 #pragma unroll
                 for (int t = 0; t < NCH; ++t) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(&qs[u * DIM + 64 * t + 4 * i]);
+                    // volatile: keep the query fragment an LDS read per use — hoisted out of the row
+                    // loop the NQ x NCH fragments would need NQ*48 registers
+                    const f32x4 v = *reinterpret_cast<const volatile f32x4*>(&qs[u * DIM + 64 * t + 4 * i]);
                     d0 = __builtin_fmaf(v.x, x[t].x, d0); d1 = __builtin_fmaf(v.y, x[t].y, d1);
                     d2 = __builtin_fmaf(v.z, x[t].z, d2); d3 = __builtin_fmaf(v.w, x[t].w, d3);
                 }

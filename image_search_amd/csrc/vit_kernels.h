@@ -473,223 +473,52 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
         }
 }
 
-// ------------------------------------------------------------------ bf16 GEMM, 256x256x64 tiles
-// The large-M form: 8 waves (2 along m x 4 along n), each wave a 128(m) x 64(n) slab =
-// 8 x 4 MFMA 16x16x32 tiles (128 accumulator registers), 24 ds_read_b128 per 64 MFMAs.
-// LDS: 2 buffers x (X 256 rows x 128 B | W 256 rows x 128 B) = 128 KiB, one workgroup per CU.
-// Same staging (global_load_lds_dwordx4, source-side XOR swizzle) and fragment addressing as
-// the 128x128 kernel.  M % 256 == 0, N % 256 == 0, K % 64 == 0.
-template <int EPI, typename TO>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __restrict__ X,
-                                                               const bf16_t* __restrict__ W,
-                                                               const float* __restrict__ bias, void* __restrict__ out,
-                                                               int N, int K, int ldo) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x (X 32 KiB | W 32 KiB)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3, g = lane >> 4, l15 = lane & 15;
-    const int nt = N / 256;
-    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = wg / nt, tn = wg % nt;
-    const size_t m0 = (size_t)tm * 256;
-    const int n0 = tn * 256;
-
-    const int rr = lane >> 3, p = lane & 7;
-    const unsigned char* xsrc =
-        reinterpret_cast<const unsigned char*>(X) + ((m0 + 32 * wave + rr) * K + 8 * (p ^ rr)) * 2;
-    const unsigned char* wsrc =
-        reinterpret_cast<const unsigned char*>(W) + (((size_t)n0 + 32 * wave + rr) * K + 8 * (p ^ rr)) * 2;
-    const size_t row8 = (size_t)8 * K * 2;
-    auto stage = [&](int buf, int kt) {
-        unsigned char* xb = smem + buf * 65536 + wave * 4096;
-        unsigned char* wb = xb + 32768;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(xsrc + j * row8 + (size_t)kt * 128, xb + j * 1024);
-            glds16(wsrc + j * row8 + (size_t)kt * 128, wb + j * 1024);
-        }
-    };
-
-    v4f acc[4][8];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[a][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-
-    const int sw = lane & 7;
-    const int a_off = 32768 + (wn * 64 + l15) * 128;  // W tile rows (MFMA A operand)
-    const int b_off = (wm * 128 + l15) * 128;          // X tile rows (MFMA B operand)
-    auto compute = [&](int buf) {
-        const unsigned char* base = smem + buf * 65536;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ch = ((4 * ks + g) ^ sw) << 4;
-            bf16x8 a[4], b[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048 + ch);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) b[i] = *reinterpret_cast<const bf16x8*>(base + b_off + i * 2048 + ch);
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ni], b[mi], acc[ni][mi], 0, 0, 0);
-        }
-    };
-
-    const int nk = K / 64;
-    stage(0, 0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-        stage(cur ^ 1, kt + 1);
-        compute(cur);
-        __syncthreads();
-        cur ^= 1;
-    }
-    compute(cur);
-
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const size_t m = m0 + wm * 128 + mi * 16 + l15;
-            const int n = n0 + wn * 64 + ni * 16 + 4 * g;
-            epilogue4<EPI, TO, true>(acc[ni][mi], bias, out, m, n, ldo);
-        }
-}
-
-// ------------------------------------------------------------------ bf16 GEMM, 256x256x64, pipelined
-// Same tile and wave layout as gemm_bf16_256_kernel, but the HBM/L2 -> LDS stream never
-// drains: each 64-deep K tile is staged as four 16 KiB half-tiles (X rows of quadrant-row
-// 0 / 1, W rows of quadrant-column 0 / 1), one half-tile per phase, running four phases
-// ahead of its first use; a phase computes one 64(m) x 32(n) quadrant of every wave's slab
-// (16 MFMA) in the snake order (0,0) (0,1) (1,1) (1,0) so the X / W fragments of the shared
-// half stay in registers.  Waits are counted (s_waitcnt vmcnt(4) leaves two half-tiles in
-// flight) and the barrier is the raw s_barrier, because __syncthreads() would drain the
-// LDS-DMA queue (cdna_hip_programming.md §5 "Pipelining across barriers").
-// LDS: 2 buffers x [XH0 | XH1 | WH0 | WH1] x 16 KiB = 128 KiB.
-//   XH[h] LDS row 64*wm + r  = tile row 128*wm + 64*h + r   (r < 64)
-//   WH[h] LDS row 32*wn + r  = tile row  64*wn + 32*h + r   (r < 32)
-template <int EPI, typename TO>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_256p_kernel(const bf16_t* __restrict__ X,
-                                                                const bf16_t* __restrict__ W,
-                                                                const float* __restrict__ bias, void* __restrict__ out,
-                                                                int N, int K, int ldo) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3, g = lane >> 4, l15 = lane & 15;
-    const int nt = N / 256;
-    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = wg / nt, tn = wg % nt;
-    const size_t m0 = (size_t)tm * 256;
-    const int n0 = tn * 256;
-
-    // staging: wave w fills LDS rows [16w, 16w+16) of every half-tile (2 wave-instructions)
-    const int rr = lane >> 3, p = lane & 7;
-    const size_t Kb = (size_t)K * 2;
-    const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(X) +
-                                (m0 + 128 * (wave >> 2) + 16 * (wave & 3) + rr) * Kb + 16 * (p ^ rr);
-    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(W) +
-                                ((size_t)n0 + 64 * (wave >> 1) + 16 * (wave & 1) + rr) * Kb + 16 * (p ^ rr);
-    // half-tile index i: 0 = XH0, 1 = WH0, 2 = WH1, 3 = XH1 (order of first use)
-    auto stage_half = [&](int buf, int kt, int i) {
-        const bool is_x = (i == 0 || i == 3);
-        const int h = (i >= 2) ? 1 : 0;
-        unsigned char* dst = smem + buf * 65536 + (is_x ? 0 : 32768) + h * 16384 + wave * 2048;
-        const unsigned char* src = (is_x ? xsrc + (size_t)64 * h * Kb : wsrc + (size_t)32 * h * Kb) + (size_t)kt * 128;
-        glds16(src, dst);
-        glds16(src + 8 * Kb, dst + 1024);
-    };
-
-    v4f acc[4][8];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[a][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-
-    const int sw = lane & 7;
-    const int x_off = (wm * 64 + l15) * 128;          // + mh*16384 + i*2048
-    const int w_off = 32768 + (wn * 32 + l15) * 128;  // + nh*16384 + i*2048
-    bf16x8 xf[2][4], wf[2][2];                         // [ks][tile]
-    auto load_x = [&](const unsigned char* base, int mh) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                xf[ks][i] = *reinterpret_cast<const bf16x8*>(base + x_off + mh * 16384 + i * 2048 + (((4 * ks + g) ^ sw) << 4));
-    };
-    auto load_w = [&](const unsigned char* base, int nh) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                wf[ks][i] = *reinterpret_cast<const bf16x8*>(base + w_off + nh * 16384 + i * 2048 + (((4 * ks + g) ^ sw) << 4));
-    };
-#define MI_QUADRANT(MH, NH)                                                                                   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          _Pragma("unroll") for (int im = 0; im < 4; ++im)                                                          _Pragma("unroll") for (int in = 0; in < 2; ++in)                                                              acc[2 * NH + in][4 * MH + im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                      wf[ks][in], xf[ks][im], acc[2 * NH + in][4 * MH + im], 0, 0, 0);
-#define MI_PHASE_SYNC(N)                                       asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");     __builtin_amdgcn_s_barrier();
-
-    const int nk = K / 64;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) stage_half(0, 0, i);
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-        const int b = kt & 1;
-        const unsigned char* base = smem + b * 65536;
-        MI_PHASE_SYNC(4)
-        stage_half(b ^ 1, kt + 1, 0);
-        load_x(base, 0); load_w(base, 0);
-        MI_QUADRANT(0, 0)
-        MI_PHASE_SYNC(4)
-        stage_half(b ^ 1, kt + 1, 1);
-        load_w(base, 1);
-        MI_QUADRANT(0, 1)
-        MI_PHASE_SYNC(4)
-        stage_half(b ^ 1, kt + 1, 2);
-        load_x(base, 1);
-        MI_QUADRANT(1, 1)
-        MI_PHASE_SYNC(4)
-        stage_half(b ^ 1, kt + 1, 3);
-        load_w(base, 0);
-        MI_QUADRANT(1, 0)
-    }
-    {
-        const unsigned char* base = smem + ((nk - 1) & 1) * 65536;
-        MI_PHASE_SYNC(4)
-        load_x(base, 0); load_w(base, 0);
-        MI_QUADRANT(0, 0)
-        MI_PHASE_SYNC(2)
-        load_w(base, 1);
-        MI_QUADRANT(0, 1)
-        MI_PHASE_SYNC(0)
-        load_x(base, 1);
-        MI_QUADRANT(1, 1)
-        load_w(base, 0);
-        MI_QUADRANT(1, 0)
-    }
-#undef MI_QUADRANT
-#undef MI_PHASE_SYNC
-
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const size_t m = m0 + wm * 128 + mi * 16 + l15;
-            const int n = n0 + wn * 64 + ni * 16 + 4 * g;
-            epilogue4<EPI, TO, true>(acc[ni][mi], bias, out, m, n, ldo);
-        }
-}
-
 // ------------------------------------------------------------------ bf16 GEMM, persistent form
-// gemm_bf16_256p_kernel's pipeline made persistent: gridDim.x <= #CUs workgroups each walk
-// tiles lb, lb+G, ...; the half-tile stream simply continues across the tile boundary (the
-// first K tile of the next tile is staged during the last K tile of the current one) and
-// the epilogue's 16 stores per lane are left in flight, counted, while the next tile
-// computes (vmcnt counts loads, stores and LDS-DMA together in issue order: the first K tile
-// after an epilogue waits vmcnt(4+16+1 bias DMA)) — instead of every CU draining its 128 KiB of output
-// at the same moment.  All addressing is SGPR descriptor + 32-bit offsets (buffer_load ... lds,
-// buffer_store): one VGPR per operand for the per-lane part, everything per-tile is scalar.
-// Operands and the output must each be < 4 GiB.
+// The large-M GEMM of the tower.  256x256x64 tiles, 8 waves (2 along m x 4 along n), each wave a
+// 128(m) x 64(n) slab = 8 x 4 MFMA 16x16x32 tiles (128 accumulator registers).
+// LDS: 2 buffers x [XH0 | XH1 | WH0 | WH1] x 16 KiB = 128 KiB (+ 18 KiB epilogue patches + 2 KiB bias):
+//   XH[h] LDS row 64*wm + r  = tile row 128*wm + 64*h + r   (r < 64)   — the X rows of quadrant-row h
+//   WH[h] LDS row 32*wn + r  = tile row  64*wn + 32*h + r   (r < 32)   — the W rows of quadrant-column h
+// The HBM/L2 -> LDS stream never drains: each K tile is staged as those four 16-KiB half-tiles by
+// `buffer_load ... lds` (1 KiB = 8 rows of 128 B per wave-instruction, LDS image linear, the 16-byte
+// chunk index XOR-swizzled with row&7 on the SOURCE address and on the ds_read_b128 address), one
+// half-tile per phase, four phases ahead of its first use.  A phase computes one 64 x 32 quadrant of
+// every wave's slab (16 MFMA) in the snake order (0,0) (0,1) (1,1) (1,0), so the fragments of the
+// shared half stay in registers.  Waits are counted (`s_waitcnt vmcnt(4)` leaves two half-tiles in
+// flight) and barriers are raw `s_barrier` (3 per K tile) — `__syncthreads()` would drain the LDS-DMA
+// queue (cdna_hip_programming.md §5 "Pipelining across barriers").
+// Persistent: gridDim.x <= #CUs workgroups walk tiles lb, lb+G, ...; the half-tile stream simply
+// continues across the tile boundary (the first K tile of the next tile is staged during the last K
+// tile of the current one) and the epilogue's 16 stores per lane are left in flight, counted, while
+// the next tile computes (vmcnt counts loads, stores and LDS-DMA together in issue order: the first
+// K tile after an epilogue waits vmcnt(4+16+1 bias DMA)) — instead of every CU draining its 128 KiB
+// of output at the same moment.  All addressing is SGPR descriptor + 32-bit offsets: one VGPR per
+// operand for the per-lane part, everything per-tile is scalar.  Operands and output < 4 GiB each.
+// Measured ladder on the ViT-L/14 b=256 shapes (M = 65 792; qkv / out / fc1 / fc2, TFLOP/s):
+//   128x128 two-barrier kernel            620 / 830 / 700 / 880
+//   256x256, stage-all-then-compute       820 / 810 / 860 / 990
+//   + half-tile pipeline, counted vmcnt   900 / 850 / 950 / 1100
+//   + persistent, async row-wise epilogue 1060 / 960 / 1070 / 1100
+//   + split last round                    1060 / 1040 / 1090 / 1200
+// Visit index -> tile, L2-aware.  Workgroups of one XCD (consecutive logical ids after xcd_remap)
+// run, round after round, an 8 (m) x 4 (n) patch of tiles: the four W tiles stay in that XCD's L2
+// across rounds and each X panel is fetched by 4 workgroups of one XCD at about the same time,
+// instead of every XCD streaming every W tile every round.  Full rounds only (v < n_full); the
+// leftover tiles keep their position.  Returns tm in .x, tn in .y.
+struct TileMN { int tm, tn; };
+__device__ __forceinline__ TileMN tile_of_visit(int v, int G, int nt, int mt, int n_full) {
+    if (n_full < 0) return {v / nt, v % nt};  // natural order (debug / A-B)
+    int seq = v;
+    const int rounds = n_full / G;  // complete rounds of G tiles; anything after keeps its position
+    if (v < rounds * G && (G & 7) == 0) {
+        const int per = G >> 3, lbv = v % G, r = v / G;
+        seq = (lbv / per) * (rounds * per) + r * per + (lbv % per);
+    }
+    const int np = (nt & 3) == 0 ? 4 : nt;  // n-tiles per group
+    const int grp = seq / (mt * np), rem = seq % (mt * np);
+    return {rem / np, grp * np + rem % np};
+}
+
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -704,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
                                                                    const bf16_t* __restrict__ W,
                                                                    const float* __restrict__ bias,
                                                                    void* __restrict__ out, int M, int N, int K,
-                                                                   int ldo, int n_tiles, int n_full) {
+                                                                   int ldo, int n_tiles, int n_full, int l2_order) {
     static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU, "the persistent form stores bf16 with bias");
     static_assert(sizeof(TO) == 2, "bf16 output");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 128 KiB staging + 18 KiB patches + 2 KiB bias
@@ -774,19 +603,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
     // whole queue with vmcnt(0) at the first use of an ordinary load issued beside LDS-DMA)
     const rsrc_t br = make_rsrc(bias, (uint32_t)N * 4u);
     unsigned char* bias_lds = smem + 131072 + 18432 + wave * 256;
-    auto stage_bias = [&](int t) {
+    auto stage_bias = [&](int tn) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (__attribute__((address_space(3))) void*)bias_lds, 4,
-                                                 (uint32_t)lane * 4u, (uint32_t)((t % nt) * 256 + wn * 64) * 4u, 0, 0);
+                                                 (uint32_t)lane * 4u, (uint32_t)(tn * 256 + wn * 64) * 4u, 0, 0);
     };
     const int nk = K / 64;
     int b = 0, kt = 0;
-    uint32_t xs = (uint32_t)(tile / nt) * 256u * Kb, ws = (uint32_t)(tile % nt) * 256u * Kb;
+    const int mt = M / 256;
+    TileMN cur = tile_of_visit(tile, G, nt, mt, l2_order ? n_full : -1);
+    uint32_t xs = (uint32_t)cur.tm * 256u * Kb, ws = (uint32_t)cur.tn * 256u * Kb;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[a][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
     if (tile < n_full) {
-    stage_bias(tile);  // oldest op of the stream
+    stage_bias(cur.tn);  // oldest op of the stream
 #pragma unroll
     for (int i = 0; i < 4; ++i) stage_half(0, xs, ws, 0, i);
     bool after_epilogue = false;
@@ -798,8 +629,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
         const int next = tile + G;
         const bool has_next = next < n_full;
         // what the four phases of this K tile stage: the next K tile of this tile, or K tile 0 of the next
-        const uint32_t s_x = last_kt ? (uint32_t)(next / nt) * 256u * Kb : xs;
-        const uint32_t s_w = last_kt ? (uint32_t)(next % nt) * 256u * Kb : ws;
+        const TileMN nxt = tile_of_visit(next, G, nt, mt, l2_order ? n_full : -1);
+        const uint32_t s_x = last_kt ? (uint32_t)nxt.tm * 256u * Kb : xs;
+        const uint32_t s_w = last_kt ? (uint32_t)nxt.tn * 256u * Kb : ws;
         const int s_kt = last_kt ? 0 : kt + 1;
         const bool do_stage = !last_kt || has_next;
         const int mode = !do_stage ? 2 : ((after_epilogue && kt == 0) ? 1 : 0);
@@ -817,8 +649,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
         // (16 rows x 144 B, beyond the two staging buffers) so that the global stores are whole
         // 128-byte row segments, 16 bytes per lane: exactly 16 stores per lane, left in flight.
         __builtin_amdgcn_sched_barrier(0);
-        const int n0 = (tile % nt) * 256;
-        const uint32_t o_tile = ((uint32_t)(tile / nt) * 256u * (uint32_t)ldo + (uint32_t)n0) * 2u;
+        const int n0 = cur.tn * 256;
+        const uint32_t o_tile = ((uint32_t)cur.tm * 256u * (uint32_t)ldo + (uint32_t)n0) * 2u;
         v4f bv[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) bv[ni] = *reinterpret_cast<const v4f*>(bias_lds + (ni * 16 + 4 * g) * 4);
@@ -856,10 +688,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
         __builtin_amdgcn_sched_barrier(0);
         if (!has_next) break;
         tile = next;
+        cur = nxt;
         xs = s_x; ws = s_w;
         kt = 0;
         after_epilogue = true;
-        stage_bias(tile);  // one more counted op between the stores and the next K tile
+        stage_bias(cur.tn);  // one more counted op between the stores and the next K tile
     }
     }  // full tiles
 
@@ -870,10 +703,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
     const int n_tasks = (n_tiles - n_full) * 4;
     for (int task = lb; task < n_tasks; task += G) {
         const int t = n_full + (task >> 2), mh = (task >> 1) & 1, nh = task & 1;
+        const TileMN tt = tile_of_visit(t, G, nt, mt, l2_order ? n_full : -1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const uint32_t txs = (uint32_t)(t / nt) * 256u * Kb + 64u * mh * Kb, tws = (uint32_t)(t % nt) * 256u * Kb + 32u * nh * Kb;
-        stage_bias(t);
+        const uint32_t txs = (uint32_t)tt.tm * 256u * Kb + 64u * mh * Kb, tws = (uint32_t)tt.tn * 256u * Kb + 32u * nh * Kb;
+        stage_bias(tt.tn);
         stage_half(0, txs, tws, 0, 0); stage_half(0, txs, tws, 0, 1);
         if (nk > 1) { stage_half(1, txs, tws, 1, 0); stage_half(1, txs, tws, 1, 1); }
         for (int kq = 0; kq < nk; ++kq) {
@@ -893,7 +727,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) bq[ni] = *reinterpret_cast<const v4f*>(bias_lds + (32 * nh + ni * 16 + 4 * g) * 4);
         unsigned char* patch = smem + 131072 + wave * 2304;
-        const uint32_t q_tile = ((uint32_t)(t / nt) * 256u * (uint32_t)ldo + (uint32_t)((t % nt) * 256)) * 2u;
+        const uint32_t q_tile = ((uint32_t)tt.tm * 256u * (uint32_t)ldo + (uint32_t)(tt.tn * 256)) * 2u;
         const uint32_t q_lane = ((uint32_t)(wm * 128 + 64 * mh + (lane >> 2)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 32 * nh + 8 * (lane & 3))) * 2u;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
@@ -932,30 +766,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
 //   per K tile:  P0 reads W1  | P1 reads X1 | P2 reads nothing | P3 reads X0', W0' of the next K tile
 //   waits:       P0, P1, P3 (vmcnt(4): two half-tiles stay in flight); 3 barriers per K tile
 // The W fragment sets swap roles every K tile, so the loop body is two K tiles (K/64 must be even).
-// Visit index -> tile, L2-aware.  Workgroups of one XCD (consecutive logical ids after xcd_remap)
-// run, round after round, an 8 (m) x 4 (n) patch of tiles: the four W tiles stay in that XCD's L2
-// across rounds and each X panel is fetched by 4 workgroups of one XCD at about the same time,
-// instead of every XCD streaming every W tile every round.  Full rounds only (v < n_full); the
-// leftover tiles keep their position.  Returns tm in .x, tn in .y.
-struct TileMN { int tm, tn; };
-__device__ __forceinline__ TileMN tile_of_visit(int v, int G, int nt, int mt, int n_full) {
-    int seq = v;
-    const int rounds = n_full / G;  // complete rounds of G tiles; anything after keeps its position
-    if (v < rounds * G && (G & 7) == 0) {
-        const int per = G >> 3, lbv = v % G, r = v / G;
-        seq = (lbv / per) * (rounds * per) + r * per + (lbv % per);
-    }
-    const int np = (nt & 3) == 0 ? 4 : nt;  // n-tiles per group
-    const int grp = seq / (mt * np), rem = seq % (mt * np);
-    return {rem / np, grp * np + rem % np};
-}
-
 template <int EPI, typename TO>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_persist2_kernel(const bf16_t* __restrict__ X,
                                                                     const bf16_t* __restrict__ W,
                                                                     const float* __restrict__ bias,
                                                                     void* __restrict__ out, int M, int N, int K,
-                                                                    int ldo, int n_tiles, int n_full) {
+                                                                    int ldo, int n_tiles, int n_full, int l2_order) {
     static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU, "the persistent form stores bf16 with bias");
     static_assert(sizeof(TO) == 2, "bf16 output");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 128 KiB staging + 18 KiB patches + 2 KiB bias
@@ -1061,7 +877,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist2_kernel(const bf16_t
     const int nk = K / 64;
     const int mt = M / 256;
     int b = 0, kt = 0;
-    TileMN cur = tile_of_visit(tile, G, nt, mt, n_full);
+    TileMN cur = tile_of_visit(tile, G, nt, mt, l2_order ? n_full : -1);
     uint32_t xs = (uint32_t)cur.tm * 256u * Kb, ws = (uint32_t)cur.tn * 256u * Kb;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -1081,7 +897,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist2_kernel(const bf16_t
     for (;;) {
         const int next = tile + G;
         const bool has_next = next < n_full;
-        const TileMN nxt = tile_of_visit(next, G, nt, mt, n_full);
+        const TileMN nxt = tile_of_visit(next, G, nt, mt, l2_order ? n_full : -1);
         const uint32_t nx = (uint32_t)nxt.tm * 256u * Kb, nw = (uint32_t)nxt.tn * 256u * Kb;
         MI_KTILE(wfA, wfB)
         MI_KTILE(wfB, wfA)
@@ -1160,7 +976,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist2_kernel(const bf16_t
                                                      (uint32_t)lane_t * 4u, (uint32_t)(tn_ * 256 + wn * 64) * 4u, 0, 0);
         };
         const int t = n_full + (task >> 2), mh = (task >> 1) & 1, nh = task & 1;
-        const TileMN tt = tile_of_visit(t, G, nt, M / 256, n_full);
+        const TileMN tt = tile_of_visit(t, G, nt, M / 256, l2_order ? n_full : -1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const uint32_t txs = (uint32_t)tt.tm * 256u * Kb + 64u * mh * Kb, tws = (uint32_t)tt.tn * 256u * Kb + 32u * nh * Kb;

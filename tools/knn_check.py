@@ -47,3 +47,16 @@ for k in (10, 64, 100, 1000):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     print(f"k={k}: {ms:.3f} ms/query  {NP*3072/ms/1e9:.1f} GB/s  ({NP*3072/ms/1e9/8000*100:.1f}% of 8 TB/s)  qps {1000/ms:.1f}")
+# batched: nq queries per table pass
+for nq in (2, 4, 8):
+    k = 10
+    di = torch.empty((nq, k), dtype=torch.int64, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(2): t.knn_device(dq.data_ptr(), nq, k, di.data_ptr(), dd.data_ptr(), s, batched=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for it in range(10): t.knn_device(dq.data_ptr(), nq, k, di.data_ptr(), dd.data_ptr(), s, batched=True)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print(f"batched nq={nq}: {ms:.3f} ms/pass  {nq*1000/ms:.0f} queries/s  pass rate {NP*3072/ms/1e6:.0f} GB/s")
