@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000, help="table rows per GPU")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
     import torch
@@ -96,9 +97,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    local = local % max(1, torch.cuda.device_count())  # rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
+    xdev = "cuda" if args.backend == "nccl" else "cpu"  # where the all-gather buffers live
 
     def barrier():
         if world > 1:
@@ -127,8 +133,8 @@ def main():
     d_q = torch.from_numpy(synth.corpus_rows(1, 0, n_q)).cuda()
     d_idx = torch.empty((1, args.k), dtype=torch.int64, device="cuda")
     d_dist = torch.empty((1, args.k), dtype=torch.float32, device="cuda")
-    g_idx = torch.empty((world, args.k), dtype=torch.int64, device="cuda")
-    g_dist = torch.empty((world, args.k), dtype=torch.float32, device="cuda")
+    g_idx = torch.empty((world, args.k), dtype=torch.int64, device=xdev)
+    g_dist = torch.empty((world, args.k), dtype=torch.float32, device=xdev)
 
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
@@ -145,8 +151,10 @@ def main():
         if marks is not None:
             marks[2].record(stream)
         if world > 1:  # the one exchange step: 12*k bytes per rank and query
-            dist.all_gather_into_tensor(g_idx, d_idx)
-            dist.all_gather_into_tensor(g_dist, d_dist)
+            if xdev == "cpu":
+                stream.synchronize()
+            dist.all_gather_into_tensor(g_idx, d_idx.to(xdev))
+            dist.all_gather_into_tensor(g_dist, d_dist.to(xdev))
             gi = g_idx.cpu().numpy().view(np.uint64)
             gd = g_dist.cpu().numpy()
             return merge_candidates(gi, gd, args.k)
@@ -166,7 +174,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -199,7 +207,7 @@ def main():
             "vit": {"images_per_sec": round(world * args.batch / (ms_vit * 1e-3), 1), "ms_per_batch": round(ms_vit, 3)},
             "knn": {"queries_per_sec": round(1e3 / ms_knn, 2), "ms_per_query": round(ms_knn, 4),
                     "rows_scanned_per_sec": round(world * args.rows / (ms_knn * 1e-3), 0), "dtype": "f32"},
-            "roofline": {"bound": "mfma", "kernel": "ViT-L/14 forward (gemm_bf16_kernel x 97 + attention/LN)",
+            "roofline": {"bound": "mfma", "kernel": "ViT-L/14 forward (gemm_bf16_persist_kernel x 96 + attention + LayerNorm, two half-chunk streams)",
                          "achieved": round(vit_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(vit_tflops / PEAK_BF16_TFLOPS, 4),
                          "traffic": pmc.get("vit_hbm_bytes") if traffic_ok else None},
