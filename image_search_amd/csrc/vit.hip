@@ -187,6 +187,7 @@ struct mi_clip {
     std::vector<void*> allocs;
     float *cls = nullptr, *pos = nullptr, *pre_w = nullptr, *pre_b = nullptr, *post_w = nullptr, *post_b = nullptr,
           *proj = nullptr;
+    void* proj_t = nullptr;  // bf16 path: projection as a GEMM operand [E][D]
     void* wpatch = nullptr;  // T [D][Kp]
     std::vector<Layer> layers;
     // workspace for `cap` images
@@ -278,7 +279,11 @@ void load_weights(mi_clip* m, const char* path) {
     m->pre_b = upload_f32(m, st.read(v + "pre_layrnorm.bias", D));
     m->post_w = upload_f32(m, st.read(v + "post_layernorm.weight", D));
     m->post_b = upload_f32(m, st.read(v + "post_layernorm.bias", D));
-    m->proj = upload_f32(m, st.read("visual_projection.weight", (int64_t)m->E * D));
+    {
+        const std::vector<float> pw = st.read("visual_projection.weight", (int64_t)m->E * D);
+        m->proj = upload_f32(m, pw);
+        if (m->precision == MI_PRECISION_BF16 && m->E % 128 == 0) m->proj_t = upload_mat(m, pw);
+    }
     {
         const std::vector<float> w = st.read(v + "embeddings.patch_embedding.weight", (int64_t)D * K);
         std::vector<float> wp((size_t)D * m->Kp, 0.0f);
@@ -537,8 +542,16 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     }
     for (int p = 0; p < parts; ++p) {
         Part& q = pt[p];
-        MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)q.n), dim3(256), 0, q.s, q.a->x, q.pending, m->post_w, m->post_b, m->proj, q.out, S, m->E, m->eps));
-        HIP_CHECK(hipGetLastError());
+        if (m->proj_t) {  // CLS rows -> post-LN (bf16, into y) -> [n,D] x [E,D]^T MFMA GEMM -> f32
+            MI_LN_DISPATCH(D, hipLaunchKernelGGL((cls_ln_kernel<VEC, NT>), dim3((unsigned)((q.n + 3) / 4)), dim3(256), 0, q.s, q.a->x, q.pending, m->post_w, m->post_b, (bf16_t*)q.a->y, (int)q.n, S, m->eps));
+            HIP_CHECK(hipGetLastError());
+            // the GEMM writes whole 128-row tiles: into the (idle) patch workspace, then the n real rows out
+            gemm<EPI_STORE_F32>(m, q.a->y, m->proj_t, nullptr, q.a->patch, q.n, m->E, D, m->E, q.s);
+            HIP_CHECK(hipMemcpyAsync(q.out, q.a->patch, q.n * m->E * sizeof(float), hipMemcpyDeviceToDevice, q.s));
+        } else {
+            MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)q.n), dim3(256), 0, q.s, q.a->x, q.pending, m->post_w, m->post_b, m->proj, q.out, S, m->E, m->eps));
+            HIP_CHECK(hipGetLastError());
+        }
     }
     for (int p = 1; p < parts; ++p) {
         HIP_CHECK(hipEventRecord(m->ev_join[p - 1], m->aux[p - 1]));

@@ -232,6 +232,23 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
     r.store(x + (size_t)row * D, lane);
 }
 
+// bf16 path: pooled[b] = LN_post(x[b*S] (+ delta[b*S])) as bf16 rows, one wave per image; the
+// projection then runs as a 128x128 MFMA GEMM over all images instead of one matvec per image.
+template <int VEC, int NT>
+__global__ __launch_bounds__(256) void cls_ln_kernel(const float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                     const float* __restrict__ w, const float* __restrict__ b,
+                                                     bf16_t* __restrict__ pooled, int n, int S, float eps) {
+    constexpr int D = 64 * VEC * NT;
+    const int lane = threadIdx.x & 63;
+    const int img = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (img >= n) return;
+    LnRow<VEC, NT> r;
+    r.load(x + (size_t)img * S * D, lane);
+    if (delta) r.add_bf16(delta + (size_t)img * S * D, lane);
+    r.normalize(w, b, eps, lane);
+    r.store(pooled + (size_t)img * D, lane);
+}
+
 // CLS pool + post-LN + bias-free projection (modeling_clip.py:641-651, :944-950):
 // out[b][e] = sum_d proj[e][d] * LN_post(x[b*S])[d].  One block per image.
 template <int VEC, int NT>
