@@ -187,7 +187,6 @@ struct mi_clip {
     std::vector<void*> allocs;
     float *cls = nullptr, *pos = nullptr, *pre_w = nullptr, *pre_b = nullptr, *post_w = nullptr, *post_b = nullptr,
           *proj = nullptr;
-    void* proj_t = nullptr;  // bf16 path: projection as a GEMM operand [E][D]
     void* wpatch = nullptr;  // T [D][Kp]
     std::vector<Layer> layers;
     // workspace for `cap` images
@@ -199,7 +198,7 @@ struct mi_clip {
     struct Act {
         float *patch = nullptr, *x = nullptr;
         void *col = nullptr, *y = nullptr, *qkv = nullptr, *h = nullptr;
-        bf16_t* delta = nullptr;  // bf16 path: out_proj / fc2 output, added to x by the next LayerNorm
+        bf16_t *delta = nullptr, *delta2 = nullptr;  // bf16 path: out_proj / fc2 outputs, added to x by LayerNorm
     } act[4];
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -279,11 +278,7 @@ void load_weights(mi_clip* m, const char* path) {
     m->pre_b = upload_f32(m, st.read(v + "pre_layrnorm.bias", D));
     m->post_w = upload_f32(m, st.read(v + "post_layernorm.weight", D));
     m->post_b = upload_f32(m, st.read(v + "post_layernorm.bias", D));
-    {
-        const std::vector<float> pw = st.read("visual_projection.weight", (int64_t)m->E * D);
-        m->proj = upload_f32(m, pw);
-        if (m->precision == MI_PRECISION_BF16 && m->E % 128 == 0) m->proj_t = upload_mat(m, pw);
-    }
+    m->proj = upload_f32(m, st.read("visual_projection.weight", (int64_t)m->E * D));
     {
         const std::vector<float> w = st.read(v + "embeddings.patch_embedding.weight", (int64_t)D * K);
         std::vector<float> wp((size_t)D * m->Kp, 0.0f);
@@ -350,6 +345,7 @@ void ensure_workspace(mi_clip* m, size_t n) {
         m->act[a].qkv = bytes(Ma * 3 * m->D * es);
         m->act[a].h = bytes(Ma * m->FF * es);
         m->act[a].delta = (bf16_t*)bytes(Ma * m->D * 2);
+        m->act[a].delta2 = (bf16_t*)bytes(Ma * m->D * 2);
     }
     (void)Mp; (void)Pp;
     m->d_out = (float*)bytes(n * m->E * 4);
@@ -436,13 +432,15 @@ void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out
         default: fail(MI_ERR_UNSUPPORTED, "hidden size %d has no LayerNorm instantiation", D); \
     }
 
-void layer_norm(mi_clip* m, float* x, const bf16_t* delta, void* y, const float* w, const float* b, size_t rows,
-                hipStream_t s) {
+void layer_norm(mi_clip* m, float* x, const bf16_t* d1, const bf16_t* d2, bool write_back, void* y, const float* w,
+                const float* b, size_t rows, hipStream_t s) {
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     if (m->precision == MI_PRECISION_F32) {
-        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<float, VEC, NT>), dim3(blocks), dim3(256), 0, s, x, delta, (float*)y, w, b, (int)rows, m->eps));
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<float, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (float*)y, w, b, (int)rows, m->eps));
+    } else if (write_back) {
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps));
     } else {
-        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT>), dim3(blocks), dim3(256), 0, s, x, delta, (bf16_t*)y, w, b, (int)rows, m->eps));
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, false>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps));
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -484,10 +482,10 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     const size_t px = (size_t)m->image * m->image * 3;
     const bool deferred = m->precision == MI_PRECISION_BF16;
     const int parts = (deferred && m->parts > 1 && n >= 32) ? m->parts : 1;
-    struct Part { size_t n, M, P; const float* img; float* out; hipStream_t s; mi_clip::Act* a; const bf16_t* pending; } pt[4];
+    struct Part { size_t n, M, P; const float* img; float* out; hipStream_t s; mi_clip::Act* a; const bf16_t *p1, *p2; } pt[4];
     for (size_t p = 0, first = 0; p < (size_t)parts; ++p) {
         const size_t np = n / parts + (p < n % parts ? 1 : 0);
-        pt[p] = {np, np * S, np * (S - 1), d_img + first * px, d_out + first * m->E, p == 0 ? s0 : m->aux[p - 1], &m->act[p], nullptr};
+        pt[p] = {np, np * S, np * (S - 1), d_img + first * px, d_out + first * m->E, p == 0 ? s0 : m->aux[p - 1], &m->act[p], nullptr, nullptr};
         first += np;
     }
     if (parts > 1) {
@@ -515,12 +513,13 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
         HIP_CHECK(hipGetLastError());
     }
     // fp32 path: the residual add is the GEMM epilogue (x += acc + bias, fp32 read-modify-write).
-    // bf16 path: out_proj / fc2 store a bf16 `delta` (a pure, asynchronous store from the persistent
-    // GEMM) and the LayerNorm that follows — which streams x anyway — does x += delta.
+    // bf16 path: out_proj / fc2 store bf16 `delta` / `delta2` (pure, asynchronous stores from the
+    // persistent GEMM).  LN2 normalises x + delta without writing x; the next LN1 forms
+    // (x + delta) + delta2 — the same order — writes it back and normalises it.
     for (const Layer& ly : m->layers) {
         for (int p = 0; p < parts; ++p) {
             Part& q = pt[p];
-            layer_norm(m, q.a->x, q.pending, q.a->y, ly.ln1w, ly.ln1b, q.M, q.s);
+            layer_norm(m, q.a->x, q.p1, q.p2, true, q.a->y, ly.ln1w, ly.ln1b, q.M, q.s);
             gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, D, 3 * D, q.s);
             attention(m, q.a->qkv, q.a->y, q.n, q.s);
         }
@@ -528,13 +527,13 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
             Part& q = pt[p];
             if (deferred) {
                 gemm<EPI_BIAS>(m, q.a->y, ly.wo, ly.bo, q.a->delta, q.M, D, D, D, q.s);
-                layer_norm(m, q.a->x, q.a->delta, q.a->y, ly.ln2w, ly.ln2b, q.M, q.s);
+                layer_norm(m, q.a->x, q.a->delta, nullptr, false, q.a->y, ly.ln2w, ly.ln2b, q.M, q.s);
                 gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, D, FF, q.s);
-                gemm<EPI_BIAS>(m, q.a->h, ly.w2, ly.b2, q.a->delta, q.M, D, FF, D, q.s);
-                q.pending = q.a->delta;
+                gemm<EPI_BIAS>(m, q.a->h, ly.w2, ly.b2, q.a->delta2, q.M, D, FF, D, q.s);
+                q.p1 = q.a->delta; q.p2 = q.a->delta2;
             } else {
                 gemm<EPI_BIAS_RESID>(m, q.a->y, ly.wo, ly.bo, q.a->x, q.M, D, D, D, q.s);
-                layer_norm(m, q.a->x, nullptr, q.a->y, ly.ln2w, ly.ln2b, q.M, q.s);
+                layer_norm(m, q.a->x, nullptr, nullptr, true, q.a->y, ly.ln2w, ly.ln2b, q.M, q.s);
                 gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, D, FF, q.s);
                 gemm<EPI_BIAS_RESID>(m, q.a->h, ly.w2, ly.b2, q.a->x, q.M, D, FF, D, q.s);
             }
@@ -542,16 +541,9 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     }
     for (int p = 0; p < parts; ++p) {
         Part& q = pt[p];
-        if (m->proj_t) {  // CLS rows -> post-LN (bf16, into y) -> [n,D] x [E,D]^T MFMA GEMM -> f32
-            MI_LN_DISPATCH(D, hipLaunchKernelGGL((cls_ln_kernel<VEC, NT>), dim3((unsigned)((q.n + 3) / 4)), dim3(256), 0, q.s, q.a->x, q.pending, m->post_w, m->post_b, (bf16_t*)q.a->y, (int)q.n, S, m->eps));
-            HIP_CHECK(hipGetLastError());
-            // the GEMM writes whole 128-row tiles: into the (idle) patch workspace, then the n real rows out
-            gemm<EPI_STORE_F32>(m, q.a->y, m->proj_t, nullptr, q.a->patch, q.n, m->E, D, m->E, q.s);
-            HIP_CHECK(hipMemcpyAsync(q.out, q.a->patch, q.n * m->E * sizeof(float), hipMemcpyDeviceToDevice, q.s));
-        } else {
-            MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)q.n), dim3(256), 0, q.s, q.a->x, q.pending, m->post_w, m->post_b, m->proj, q.out, S, m->E, m->eps));
-            HIP_CHECK(hipGetLastError());
-        }
+        // fp32 in both precisions: the embedding that goes to the table is not rounded to bf16 anywhere here
+        MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8)), dim3(256), 0, q.s, q.a->x, q.p1, q.p2, m->post_w, m->post_b, m->proj, q.out, (int)q.n, S, m->E, m->eps));
+        HIP_CHECK(hipGetLastError());
     }
     for (int p = 1; p < parts; ++p) {
         HIP_CHECK(hipEventRecord(m->ev_join[p - 1], m->aux[p - 1]));
@@ -764,7 +756,7 @@ int mi_op_layernorm(int device, int precision, const float* x, const float* w, c
         float* dw = (float*)sc.up(MI_PRECISION_F32, w, 1, d, 1);
         float* db = (float*)sc.up(MI_PRECISION_F32, b, 1, d, 1);
         void* dy = sc.bytes(rows * d * 4);
-        layer_norm(&m, dx, nullptr, dy, dw, db, rows, nullptr);
+        layer_norm(&m, dx, nullptr, nullptr, true, dy, dw, db, rows, nullptr);
         HIP_CHECK(hipDeviceSynchronize());
         sc.down(precision, dy, y, rows * d);
     });

@@ -192,23 +192,25 @@ struct LnRow {
     }
 };
 
-// y[row] = LN(x[row]) for row < rows; 4 rows per 256-thread block.  With `delta` (bf16 path):
-// x[row] += delta[row] first, written back — the residual add of the preceding out_proj / fc2,
-// whose GEMM epilogue is then a pure bf16 store.
-template <typename T, int VEC, int NT>
-__global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
-                                                 T* __restrict__ y, const float* __restrict__ w,
-                                                 const float* __restrict__ b, int rows, float eps) {
+// y[row] = LN(x[row] + d1[row] + d2[row]) for row < rows; 4 rows per 256-thread block (bf16 path:
+// the residual adds of the preceding out_proj / fc2, whose GEMM epilogues are pure bf16 stores).
+//   d1, d2 nullable.  WRITE_BACK: x[row] <- the sum (once per layer, in LN1); LN2 only reads
+//   x + d1 — it is added again, in the same order, by the next LN1, which saves one fp32 write of
+//   the residual stream per layer.
+template <typename T, int VEC, int NT, bool WRITE_BACK>
+__global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const bf16_t* __restrict__ d1,
+                                                 const bf16_t* __restrict__ d2, T* __restrict__ y,
+                                                 const float* __restrict__ w, const float* __restrict__ b, int rows,
+                                                 float eps) {
     constexpr int D = 64 * VEC * NT;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     LnRow<VEC, NT> r;
     r.load(x + (size_t)row * D, lane);
-    if (delta) {
-        r.add_bf16(delta + (size_t)row * D, lane);
-        r.store(x + (size_t)row * D, lane);
-    }
+    if (d1) r.add_bf16(d1 + (size_t)row * D, lane);
+    if (d2) r.add_bf16(d2 + (size_t)row * D, lane);
+    if (WRITE_BACK && (d1 || d2)) r.store(x + (size_t)row * D, lane);
     r.normalize(w, b, eps, lane);
     r.store(y + (size_t)row * D, lane);
 }
@@ -232,48 +234,52 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
     r.store(x + (size_t)row * D, lane);
 }
 
-// bf16 path: pooled[b] = LN_post(x[b*S] (+ delta[b*S])) as bf16 rows, one wave per image; the
-// projection then runs as a 128x128 MFMA GEMM over all images instead of one matvec per image.
-template <int VEC, int NT>
-__global__ __launch_bounds__(256) void cls_ln_kernel(const float* __restrict__ x, const bf16_t* __restrict__ delta,
-                                                     const float* __restrict__ w, const float* __restrict__ b,
-                                                     bf16_t* __restrict__ pooled, int n, int S, float eps) {
-    constexpr int D = 64 * VEC * NT;
-    const int lane = threadIdx.x & 63;
-    const int img = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (img >= n) return;
-    LnRow<VEC, NT> r;
-    r.load(x + (size_t)img * S * D, lane);
-    if (delta) r.add_bf16(delta + (size_t)img * S * D, lane);
-    r.normalize(w, b, eps, lane);
-    r.store(pooled + (size_t)img * D, lane);
-}
-
 // CLS pool + post-LN + bias-free projection (modeling_clip.py:641-651, :944-950):
-// out[b][e] = sum_d proj[e][d] * LN_post(x[b*S])[d].  One block per image.
+// out[b][e] = sum_d proj[e][d] * LN_post(x[b*S] (+ d1 + d2))[d], all fp32.  One block per 8 images:
+// their pooled rows sit in LDS and every projection row is fetched once per block, not per image.
 template <int VEC, int NT>
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const bf16_t* __restrict__ delta,
-                                                   const float* __restrict__ w, const float* __restrict__ b,
-                                                   const float* __restrict__ proj, float* __restrict__ out, int S,
-                                                   int E, float eps) {
-    constexpr int D = 64 * VEC * NT;
-    __shared__ float pooled[D];
+                                                   const bf16_t* __restrict__ delta2, const float* __restrict__ w,
+                                                   const float* __restrict__ b, const float* __restrict__ proj,
+                                                   float* __restrict__ out, int n, int S, int E, float eps) {
+    constexpr int D = 64 * VEC * NT, IMG = 8;
+    __shared__ float pooled[IMG][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (wave == 0) {
+    const int img0 = blockIdx.x * IMG;
+    for (int i = wave; i < IMG; i += 4) {
+        const int img = img0 + i;
         LnRow<VEC, NT> r;
-        r.load(x + (size_t)blockIdx.x * S * D, lane);
-        if (delta) r.add_bf16(delta + (size_t)blockIdx.x * S * D, lane);
-        r.normalize(w, b, eps, lane);
-        r.store(pooled, lane);
+        if (img < n) {
+            r.load(x + (size_t)img * S * D, lane);
+            if (delta) r.add_bf16(delta + (size_t)img * S * D, lane);
+            if (delta2) r.add_bf16(delta2 + (size_t)img * S * D, lane);
+            r.normalize(w, b, eps, lane);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC * NT; ++j) r.v[j] = 0.0f;
+        }
+        r.store(&pooled[i][0], lane);
     }
     __syncthreads();
     for (int e = wave; e < E; e += 4) {
         const float* pr = proj + (size_t)e * D;
-        float acc = 0.0f;
-#pragma unroll 4
-        for (int d = lane; d < D; d += 64) acc = __builtin_fmaf(pr[d], pooled[d], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) out[(size_t)blockIdx.x * E + e] = acc;
+        float acc[IMG];
+#pragma unroll
+        for (int i = 0; i < IMG; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float pw[VEC];
+            ld_vec<VEC>(pw, pr + (t * 64 + lane) * VEC);
+#pragma unroll
+            for (int i = 0; i < IMG; ++i)
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) acc[i] = __builtin_fmaf(pw[c], pooled[i][(t * 64 + lane) * VEC + c], acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < IMG; ++i) {
+            const float v = wave_sum(acc[i]);
+            if (lane == 0 && img0 + i < n) out[(size_t)(img0 + i) * E + e] = v;
+        }
     }
 }
 
