@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 // S_CT > 0: the token count is a compile-time constant (launcher checks S == S_CT), so every
 // "does this key tile exist / straddle S" test folds away; S_CT == 0 keeps them at run time.
 template <int S_PAD, int S_CT>
-__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                            int S_rt, int D, int H) {
     constexpr int NKT = S_PAD / 16, NPV = S_PAD / 32;
     const int S = S_CT > 0 ? S_CT : S_rt;
@@ -1193,18 +1193,27 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
         qf[0] = qn[0]; qf[1] = qn[1];
         load_q(qn, qt + 4 < nqt ? qt + 4 : qt);  // next tile's queries travel while this one computes
 
+        // K fragments run KPF key tiles ahead of the MFMAs that consume them (hipcc waits on an LDS
+        // read right at its first use: without the ring every key tile exposed its ds_read latency)
+        constexpr int KPF = 4;
         v4f sc[NKT];
+        bf16x8 kfr[KPF][2];
+        auto load_k = [&](bf16x8 (&dst)[2], int T) {
+            const int row = 16 * T + l15;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                dst[ks] = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + (((4 * ks + g) ^ (row & 7)) << 4));
+        };
+#pragma unroll
+        for (int T = 0; T < KPF; ++T)
+            if (T < NKT && T < nkt) load_k(kfr[T], T);
 #pragma unroll
         for (int T = 0; T < NKT; ++T) {
             sc[T] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
             if (T < nkt) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int row = 16 * T + l15;
-                    const bf16x8 kf =
-                        *reinterpret_cast<const bf16x8*>(Ks + row * 128 + (((4 * ks + g) ^ (row & 7)) << 4));
-                    sc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[T], 0, 0, 0);
-                }
+                sc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[T % KPF][0], qf[0], sc[T], 0, 0, 0);
+                sc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[T % KPF][1], qf[1], sc[T], 0, 0, 0);
+                if (T + KPF < NKT && T + KPF < nkt) load_k(kfr[T % KPF], T + KPF);
             }
         }
         // sc[T][e] = (K Q^T)[key 16T + 4g + e][query l15]; mask the tile that straddles S
@@ -1246,22 +1255,30 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16_t* __restr
         v4f o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-        // transposed-read address of this lane inside its 16-lane group: row q, columns 4p..4p+3
+        // transposed-read address of this lane inside its 16-lane group: row q, columns 4p..4p+3;
+        // the V fragments of step s+1 are fetched before the MFMAs of step s
         const int tq = l15 >> 2, tp = l15 & 3;
+        bf16x8 vfr[2][4];
+        auto load_v = [&](bf16x8 (&dst)[4], int s) {
+            const int key0 = 32 * s + 4 * g + tq, key1 = key0 + 16;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int c = 2 * dt + (tp >> 1), sub = (tp & 1) * 8;
+                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(Vs + key0 * 128 + ((c ^ (key0 & 7)) << 4) + sub));
+                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(Vs + key1 * 128 + ((c ^ (key1 & 7)) << 4) + sub));
+                dst[dt] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        };
+        load_v(vfr[0], 0);
 #pragma unroll
         for (int s = 0; s < NPV; ++s) {
             if (2 * s < nkt) {
-                const int key0 = 32 * s + 4 * g + tq, key1 = key0 + 16;
+                if (s + 1 < NPV && 2 * (s + 1) < nkt) load_v(vfr[(s + 1) & 1], s + 1);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const int c = 2 * dt + (tp >> 1), sub = (tp & 1) * 8;
-                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(Vs + key0 * 128 + ((c ^ (key0 & 7)) << 4) + sub));
-                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(Vs + key1 * 128 + ((c ^ (key1 & 7)) << 4) + sub));
-                    const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[s], vf, o[dt], 0, 0, 0);
-                }
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[s], vfr[s & 1][dt], o[dt], 0, 0, 0);
             }
         }
         // o[dt][e] = O[query 4g + e][d = 16 dt + l15]  ->  patch[query][d] (bf16), then 16-byte row stores
