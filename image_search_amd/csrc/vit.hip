@@ -455,8 +455,8 @@ void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s) 
 #define MI_ATTN(SP, SC)                                                                                              \
     {                                                                                                                \
         static bool done = false;                                                                                    \
-        if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)attn_bf16_kernel<SP, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, SP * 256 + 8192)); done = true; } \
-        hipLaunchKernelGGL((attn_bf16_kernel<SP, SC>), dim3(blocks), dim3(256), SP * 256 + 8192, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H); \
+        if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)attn_bf16_kernel<SP, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, SP * 256)); done = true; } \
+        hipLaunchKernelGGL((attn_bf16_kernel<SP, SC>), dim3(blocks), dim3(256), SP * 256, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H); \
     }
         if (m->S == 257) MI_ATTN(288, 257)       // ViT-L/14, ViT-H/14 @224
         else if (m->S == 197) MI_ATTN(224, 197)  // ViT-B/16 @224

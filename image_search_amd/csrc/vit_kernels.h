@@ -1137,86 +1137,200 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 // ds_read_b64_tr_b16 so the same row-major image serves as the B operand.
 // Softmax runs in the exp2 domain with the 1/8 scale folded in (one fma + one v_exp
 // per score); only key tiles that hold a key >= S are masked, tiles entirely beyond S
-// are never computed.  The output tile is transposed through a wave-private LDS patch
-// so that each lane stores 16 contiguous bytes of a context row.
+// are never computed.  P V is computed transposed too, with the V columns permuted across the
+// MFMA rows, so each lane stores 2 x 16 contiguous bytes of its own query's context row; the
+// row sums come from a sixth MFMA against a fragment of ones.
 // S <= S_PAD, S_PAD % 32 == 0; the whole score row of a query lives in registers.
 // (hipcc pitfall: assembling the bf16x8 B fragment element by element from the transposed
 //  read's v4i16 result miscompiled to a splat of element 0 — use the v4bf16 builtin and
 //  __builtin_shufflevector.)
 // S_CT > 0: the token count is a compile-time constant (launcher checks S == S_CT), so every
 // "does this key tile exist / straddle S" test folds away; S_CT == 0 keeps them at run time.
-template <int S_PAD, int S_CT>
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                           int S_rt, int D, int H) {
+//
+// NQ query tiles (of 16 rows) are processed TOGETHER by a wave: with two workgroups per CU there
+// are only two waves per SIMD and the chain MFMA -> max -> exp -> pack -> MFMA is latency-bound
+// (measured: no overlap between the two resident waves), so the second tile supplies the
+// independent instructions; the K and V fragments read from LDS serve both tiles.
+template <int S_PAD, int S_CT, int NQ>
+__device__ __forceinline__ void attn_tiles(const unsigned char* __restrict__ Ks, const unsigned char* __restrict__ Vs,
+                                           const bf16_t* __restrict__ base, bf16_t* __restrict__ ctx_b, size_t ld,
+                                           int S_rt, int D, const int (&qt)[NQ], int lane) {
     constexpr int NKT = S_PAD / 16, NPV = S_PAD / 32;
     const int S = S_CT > 0 ? S_CT : S_rt;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Ks = smem;
-    unsigned char* Vs = smem + S_PAD * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
-    const int b = blockIdx.x / H, hh = blockIdx.x % H;
-    const size_t ld = (size_t)3 * D;
-    const bf16_t* base = qkv + (size_t)b * S * ld + hh * 64;
-    unsigned char* patch = smem + S_PAD * 256 + wave * 2048;  // 16 rows x 128 B, chunk ^= row & 7
-
-    // K and V go HBM -> LDS by LDS-DMA, 8 rows (1 KiB) per wave-instruction; the image is linear,
-    // the XOR swizzle is applied to the per-lane source chunk; rows >= S lie beyond the
-    // descriptor's num_records, so the hardware range check fills them with zeros.
-    {
-        const rsrc_t kvr = make_rsrc(base, (uint32_t)((size_t)S * ld * 2 - (size_t)hh * 128));
-        const int rr = lane >> 3, p = lane & 7;
-        const uint32_t voff = (uint32_t)rr * (uint32_t)(ld * 2) + 16u * (uint32_t)(p ^ rr);
-        for (int j = __builtin_amdgcn_readfirstlane(wave); j < S_PAD / 8; j += 4) {
-            const uint32_t so = (uint32_t)(8 * j) * (uint32_t)(ld * 2);
-            glds16_buf(kvr, voff, so + (uint32_t)D * 2u, Ks + j * 1024);
-            glds16_buf(kvr, voff, so + (uint32_t)D * 4u, Vs + j * 1024);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-
-    const int nqt = (S + 15) / 16;
-    const int nkt = (S + 15) / 16;                 // key tiles that hold at least one key
+    const int nkt = (S + 15) / 16;
     constexpr float C2 = 0.125f * 1.4426950408889634f;  // scale * log2(e)
-    // rotate the start so the wave that gets the extra query tile differs between co-resident workgroups
+
+    bf16x8 qf[NQ][2];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int qi = qt[u] * 16 + l15;
+        const int qc = qi < S ? qi : S - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[u][ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * ld + 32 * ks + 8 * g);
+    }
+
+    // S^T = K Q^T; K fragments run KPF key tiles ahead of their MFMAs
+    constexpr int KPF = 3;
+    v4f sc[NQ][NKT];
+    bf16x8 kfr[KPF][2];
+    auto load_k = [&](bf16x8 (&dst)[2], int T) {
+        const int row = 16 * T + l15;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            dst[ks] = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + (((4 * ks + g) ^ (row & 7)) << 4));
+    };
+#pragma unroll
+    for (int T = 0; T < KPF; ++T)
+        if (T < NKT && T < nkt) load_k(kfr[T], T);
+#pragma unroll
+    for (int T = 0; T < NKT; ++T) {
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) sc[u][T] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+        if (T < nkt) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int u = 0; u < NQ; ++u)
+                    sc[u][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[T % KPF][ks], qf[u][ks], sc[u][T], 0, 0, 0);
+            if (T + KPF < NKT && T + KPF < nkt) load_k(kfr[T % KPF], T + KPF);
+        }
+    }
+    // sc[u][T][e] = (K Q^T)[key 16T + 4g + e][query l15 of tile u]
+    bf16x8 pa[NQ][NPV];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int T = 0; T < NKT; ++T) {
+            if (T < nkt) {
+                if (16 * T + 16 > S) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (16 * T + 4 * g + e >= S) sc[u][T][e] = -INFINITY;
+                }
+                mx = fmaxf(mx, fmaxf(fmaxf(sc[u][T][0], sc[u][T][1]), fmaxf(sc[u][T][2], sc[u][T][3])));
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mc = -mx * C2;
+#pragma unroll
+        for (int s = 0; s < NPV; ++s)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int T = 2 * s + half;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pw = 0.0f;
+                    if (T < nkt) pw = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[u][T][e], C2, mc));
+                    pa[u][s][4 * half + e] = (__bf16)pw;
+                }
+            }
+    }
+    // O^T = V^T P^T with permuted V columns (see the kernel header); row sums from a fragment of ones
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    v4f o[NQ][4], osum[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        osum[u] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[u][dt] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    const int tq = l15 >> 2, tp = l15 & 3;
+    bf16x8 vfr[2][4];
+    auto load_v = [&](bf16x8 (&dst)[4], int s) {
+        const int key0 = 32 * s + 4 * g + tq, key1 = key0 + 16;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int c = 4 * (dt >> 1) + tp, sub = (dt & 1) * 8;
+            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)(Vs + key0 * 128 + ((c ^ (key0 & 7)) << 4) + sub));
+            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)(Vs + key1 * 128 + ((c ^ (key1 & 7)) << 4) + sub));
+            dst[dt] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    load_v(vfr[0], 0);
+#pragma unroll
+    for (int s = 0; s < NPV; ++s) {
+        if (2 * s < nkt) {
+            if (s + 1 < NPV && 2 * (s + 1) < nkt) load_v(vfr[(s + 1) & 1], s + 1);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int u = 0; u < NQ; ++u)
+                    o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[s & 1][dt], pa[u][s], o[u][dt], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < NQ; ++u)
+                osum[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pa[u][s], osum[u], 0, 0, 0);
+        }
+    }
+    // o[u][dt][e] = O[query l15][d = 32*(dt>>1) + 8g + 4*(dt&1) + e]; osum[u][*] = sum_key P[query l15][key]
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int qi = qt[u] * 16 + l15;
+        const float ie = __builtin_amdgcn_rcpf(osum[u][0]);
+        if (qi < S) {
+            bf16_t* dst = ctx_b + (size_t)qi * D + 8 * g;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                v4u d;
+                d.x = pack2bf(o[u][2 * w][0] * ie, o[u][2 * w][1] * ie);
+                d.y = pack2bf(o[u][2 * w][2] * ie, o[u][2 * w][3] * ie);
+                d.z = pack2bf(o[u][2 * w + 1][0] * ie, o[u][2 * w + 1][1] * ie);
+                d.w = pack2bf(o[u][2 * w + 1][2] * ie, o[u][2 * w + 1][3] * ie);
+                *reinterpret_cast<v4u*>(dst + 32 * w) = d;
+            }
+        }
+    }
+}
+
+// Two query tiles A, B software-pipelined inside one wave, written in the order the wave should
+// issue it (in-order issue: the VALU work placed between MFMAs runs while the matrix pipe works):
+//   QK(A)  |  QK(B) tile by tile  with  exp/pack(A) tile by tile  |  PV(A) step by step  with
+//   exp/pack(B) two tiles per step  |  PV(B)
+// K and V fragments come from LDS once per use (no sharing between A and B in this order, but
+// the live registers stay near 200 instead of spilling at 256).
+template <int S_PAD, int S_CT>
+__device__ __forceinline__ void attn_pair(const unsigned char* __restrict__ Ks, const unsigned char* __restrict__ Vs,
+                                          const bf16_t* __restrict__ base, bf16_t* __restrict__ ctx_b, size_t ld,
+                                          int S_rt, int D, int qtA, int qtB, int lane) {
+    constexpr int NKT = S_PAD / 16, NPV = S_PAD / 32;
+    const int S = S_CT > 0 ? S_CT : S_rt;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int nkt = (S + 15) / 16;
+    constexpr float C2 = 0.125f * 1.4426950408889634f;
+    const int tq = l15 >> 2, tp = l15 & 3;
+
     auto load_q = [&](bf16x8 (&q)[2], int qt) {
         const int qi = qt * 16 + l15;
         const int qc = qi < S ? qi : S - 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) q[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * ld + 32 * ks + 8 * g);
     };
-    bf16x8 qf[2], qn[2];
-    const int qt0 = (wave + blockIdx.x) & 3;
-    load_q(qn, qt0 < nqt ? qt0 : 0);
-    for (int qt = qt0; qt < nqt; qt += 4) {
-        qf[0] = qn[0]; qf[1] = qn[1];
-        load_q(qn, qt + 4 < nqt ? qt + 4 : qt);  // next tile's queries travel while this one computes
-
-        // K fragments run KPF key tiles ahead of the MFMAs that consume them (hipcc waits on an LDS
-        // read right at its first use: without the ring every key tile exposed its ds_read latency)
-        constexpr int KPF = 4;
-        v4f sc[NKT];
-        bf16x8 kfr[KPF][2];
-        auto load_k = [&](bf16x8 (&dst)[2], int T) {
-            const int row = 16 * T + l15;
+    auto load_k = [&](bf16x8 (&dst)[2], int T) {
+        const int row = 16 * T + l15;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                dst[ks] = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + (((4 * ks + g) ^ (row & 7)) << 4));
-        };
+        for (int ks = 0; ks < 2; ++ks)
+            dst[ks] = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + (((4 * ks + g) ^ (row & 7)) << 4));
+    };
+    auto load_v = [&](bf16x8 (&dst)[4], int s) {
+        const int key0 = 32 * s + 4 * g + tq, key1 = key0 + 16;
 #pragma unroll
-        for (int T = 0; T < KPF; ++T)
-            if (T < NKT && T < nkt) load_k(kfr[T], T);
-#pragma unroll
-        for (int T = 0; T < NKT; ++T) {
-            sc[T] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-            if (T < nkt) {
-                sc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[T % KPF][0], qf[0], sc[T], 0, 0, 0);
-                sc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[T % KPF][1], qf[1], sc[T], 0, 0, 0);
-                if (T + KPF < NKT && T + KPF < nkt) load_k(kfr[T % KPF], T + KPF);
-            }
+        for (int dt = 0; dt < 4; ++dt) {
+            const int c = 4 * (dt >> 1) + tp, sub = (dt & 1) * 8;
+            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)(Vs + key0 * 128 + ((c ^ (key0 & 7)) << 4) + sub));
+            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)(Vs + key1 * 128 + ((c ^ (key1 & 7)) << 4) + sub));
+            dst[dt] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
         }
-        // sc[T][e] = (K Q^T)[key 16T + 4g + e][query l15]; mask the tile that straddles S
+    };
+    // masked row maximum of a finished score tile set (in-lane + the two cross-lane steps)
+    auto row_max = [&](v4f (&sc)[NKT]) {
         float mx = -INFINITY;
 #pragma unroll
         for (int T = 0; T < NKT; ++T) {
@@ -1231,79 +1345,186 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mc = -mx * C2;
-        float sum = 0.0f;
-        bf16x8 pa[NPV];
-#pragma unroll
-        for (int s = 0; s < NPV; ++s) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int T = 2 * s + half;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float pw = 0.0f;
-                    if (T < nkt) pw = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[T][e], C2, mc));
-                    sum += pw;
-                    pa[s][4 * half + e] = (__bf16)pw;
-                }
-            }
-        }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-
-        v4f o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-        // transposed-read address of this lane inside its 16-lane group: row q, columns 4p..4p+3;
-        // the V fragments of step s+1 are fetched before the MFMAs of step s
-        const int tq = l15 >> 2, tp = l15 & 3;
-        bf16x8 vfr[2][4];
-        auto load_v = [&](bf16x8 (&dst)[4], int s) {
-            const int key0 = 32 * s + 4 * g + tq, key1 = key0 + 16;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const int c = 2 * dt + (tp >> 1), sub = (tp & 1) * 8;
-                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(Vs + key0 * 128 + ((c ^ (key0 & 7)) << 4) + sub));
-                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(Vs + key1 * 128 + ((c ^ (key1 & 7)) << 4) + sub));
-                dst[dt] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-        };
-        load_v(vfr[0], 0);
-#pragma unroll
-        for (int s = 0; s < NPV; ++s) {
-            if (2 * s < nkt) {
-                if (s + 1 < NPV && 2 * (s + 1) < nkt) load_v(vfr[(s + 1) & 1], s + 1);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[s], vfr[s & 1][dt], o[dt], 0, 0, 0);
-            }
-        }
-        // o[dt][e] = O[query 4g + e][d = 16 dt + l15]  ->  patch[query][d] (bf16), then 16-byte row stores
+        return -mx * C2;
+    };
+    auto exp_pack4 = [&](const v4f& sc, float mc, bool live, bf16x8& dst, int half) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float ie = __shfl(inv, 4 * g + e, 64);
-            const int r = 4 * g + e;
+            float pw = 0.0f;
+#if defined(ABL) && ABL == 3
+            if (live) pw = __builtin_fmaf(sc[e], C2, mc);
+#else
+            if (live) pw = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], C2, mc));
+#endif
+            dst[4 * half + e] = (__bf16)pw;
+        }
+    };
+    auto store_o = [&](const v4f (&o)[4], const v4f& osum, int qt) {
+        const int qi = qt * 16 + l15;
+        const float ie = __builtin_amdgcn_rcpf(osum[0]);
+        if (qi < S) {
+            bf16_t* dst = ctx_b + (size_t)qi * D + 8 * g;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const int col = 16 * dt + l15;  // bf16 column; 16-byte chunk = col >> 3
-                *reinterpret_cast<bf16_t*>(patch + r * 128 + ((((col >> 3) ^ (r & 7))) << 4) + (col & 7) * 2) =
-                    f2bf(o[dt][e] * ie);
+            for (int w = 0; w < 2; ++w) {
+                v4u d;
+                d.x = pack2bf(o[2 * w][0] * ie, o[2 * w][1] * ie);
+                d.y = pack2bf(o[2 * w][2] * ie, o[2 * w][3] * ie);
+                d.z = pack2bf(o[2 * w + 1][0] * ie, o[2 * w + 1][1] * ie);
+                d.w = pack2bf(o[2 * w + 1][2] * ie, o[2 * w + 1][3] * ie);
+                *reinterpret_cast<v4u*>(dst + 32 * w) = d;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    bf16x8 qa[2], qb[2];
+    load_q(qa, qtA);
+    load_q(qb, qtB);
+    constexpr int KPF = 3;
+    bf16x8 kfr[KPF][2];
+    v4f scA[NKT], scB[NKT];
+    // ---- QK(A): key tiles in groups of KPF; within a group all k-step-0 MFMAs, then all k-step-1
+    // (a tile's two MFMAs chain through its accumulator: issued back to back they run at half rate)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = j * 8 + (lane >> 3), c = lane & 7;
-            const v4u d = *reinterpret_cast<const v4u*>(patch + r * 128 + ((c ^ (r & 7)) << 4));
-            const int qrow = qt * 16 + r;
-            if (qrow < S) *reinterpret_cast<v4u*>(ctx + ((size_t)b * S + qrow) * D + hh * 64 + c * 8) = d;
+    for (int T = 0; T < KPF; ++T)
+        if (T < NKT && T < nkt) load_k(kfr[T], T);
+#pragma unroll
+    for (int T0 = 0; T0 < NKT; T0 += KPF) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < KPF; ++t) {
+                const int T = T0 + t;
+                if (T < NKT) {
+                    if (ks == 0) scA[T] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                    if (T < nkt) scA[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[t][ks], qa[ks], scA[T], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int t = 0; t < KPF; ++t)
+            if (T0 + KPF + t < NKT && T0 + KPF + t < nkt) load_k(kfr[t], T0 + KPF + t);
+    }
+    const float mcA = row_max(scA);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- QK(B) tile by tile, exp/pack(A) in between
+    bf16x8 paA[NPV], paB[NPV];
+#pragma unroll
+    for (int T = 0; T < KPF; ++T)
+        if (T < NKT && T < nkt) load_k(kfr[T], T);
+#pragma unroll
+    for (int T0 = 0; T0 < NKT; T0 += KPF) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < KPF; ++t) {
+                const int T = T0 + t;
+                if (T < NKT) {
+                    if (ks == 0) scB[T] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                    if (T < nkt) scB[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[t][ks], qb[ks], scB[T], 0, 0, 0);
+                }
+                // exp/pack of A's matching tile rides between the MFMAs
+                if (ks == 1 && T < NKT) exp_pack4(scA[T], mcA, T < nkt, paA[T >> 1], T & 1);
+            }
+#pragma unroll
+        for (int t = 0; t < KPF; ++t)
+            if (T0 + KPF + t < NKT && T0 + KPF + t < nkt) load_k(kfr[t], T0 + KPF + t);
+        __builtin_amdgcn_sched_barrier(0);  // keep the written interleave: hipcc otherwise regroups and spills
+    }
+    const float mcB = row_max(scB);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- PV(A) step by step, exp/pack(B) in between
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    bf16x8 vfr[2][4];
+    v4f oA[4], oB[4], sumA = {0.0f, 0.0f, 0.0f, 0.0f}, sumB = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { oA[dt] = (v4f){0.0f, 0.0f, 0.0f, 0.0f}; oB[dt] = (v4f){0.0f, 0.0f, 0.0f, 0.0f}; }
+    load_v(vfr[0], 0);
+#pragma unroll
+    for (int s = 0; s < NPV; ++s) {
+        if (2 * s < nkt) {
+            if (s + 1 < NPV && 2 * (s + 1) < nkt) load_v(vfr[(s + 1) & 1], s + 1);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#if defined(ABL) && ABL == 4
+                asm volatile("" ::"v"(vfr[s & 1][dt]), "v"(paA[s]));
+            sumA[0] = 1.0f;
+#else
+                oA[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[s & 1][dt], paA[s], oA[dt], 0, 0, 0);
+            sumA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, paA[s], sumA, 0, 0, 0);
+#endif
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        exp_pack4(scB[2 * s], mcB, 2 * s < nkt, paB[s], 0);
+        exp_pack4(scB[2 * s + 1], mcB, 2 * s + 1 < nkt, paB[s], 1);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    store_o(oA, sumA, qtA);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- PV(B)
+    load_v(vfr[0], 0);
+#pragma unroll
+    for (int s = 0; s < NPV; ++s) {
+        if (2 * s < nkt) {
+            if (s + 1 < NPV && 2 * (s + 1) < nkt) load_v(vfr[(s + 1) & 1], s + 1);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#if defined(ABL) && ABL == 4
+                asm volatile("" ::"v"(vfr[s & 1][dt]), "v"(paB[s]));
+            sumB[0] = 1.0f;
+#else
+                oB[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[s & 1][dt], paB[s], oB[dt], 0, 0, 0);
+            sumB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, paB[s], sumB, 0, 0, 0);
+#endif
+        }
+    }
+    store_o(oB, sumB, qtB);
+}
+
+template <int S_PAD, int S_CT>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bf16_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int S_rt, int D, int H) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;
+    unsigned char* Vs = smem + S_PAD * 128;
+    const int S = S_CT > 0 ? S_CT : S_rt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, hh = blockIdx.x % H;
+    const size_t ld = (size_t)3 * D;
+    const bf16_t* base = qkv + (size_t)b * S * ld + hh * 64;
+
+#if !defined(ABL) || ABL != 2  // ABL 2: no staging (LDS holds garbage)
+    // K and V go HBM -> LDS by LDS-DMA, 8 rows (1 KiB) per wave-instruction; the image is linear,
+    // the XOR swizzle is applied to the per-lane source chunk; rows >= S lie beyond the
+    // descriptor's num_records, so the hardware range check fills them with zeros.
+    {
+        const rsrc_t kvr = make_rsrc(base, (uint32_t)((size_t)S * ld * 2 - (size_t)hh * 128));
+        const int rr = lane >> 3, p = lane & 7;
+        const uint32_t voff = (uint32_t)rr * (uint32_t)(ld * 2) + 16u * (uint32_t)(p ^ rr);
+        for (int j = __builtin_amdgcn_readfirstlane(wave); j < S_PAD / 8; j += 4) {
+            const uint32_t so = (uint32_t)(8 * j) * (uint32_t)(ld * 2);
+            glds16_buf(kvr, voff, so + (uint32_t)D * 2u, Ks + j * 1024);
+            glds16_buf(kvr, voff, so + (uint32_t)D * 4u, Vs + j * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#endif
+    __syncthreads();
+#if defined(ABL) && ABL == 1  // staging only
+    if (tid < 4) ctx[(size_t)blockIdx.x * 4 + tid] = *reinterpret_cast<const bf16_t*>(Ks + tid * 2);
+    return;
+#endif
+
+    // query tiles of this wave: w', w'+4, ... with the start rotated between co-resident workgroups;
+    // they are taken two at a time, a last odd one alone
+    const int nqt = (S + 15) / 16;
+    bf16_t* ctx_b = ctx + (size_t)b * S * D + hh * 64;
+    int q0 = (wave + blockIdx.x) & 3;
+    for (; q0 + 4 < nqt; q0 += 8) {
+        attn_pair<S_PAD, S_CT>(Ks, Vs, base, ctx_b, ld, S_rt, D, q0, q0 + 4, lane);
+    }
+    if (q0 < nqt) {
+        const int one[1] = {q0};
+        attn_tiles<S_PAD, S_CT, 1>(Ks, Vs, base, ctx_b, ld, S_rt, D, one, lane);
     }
 }
 
