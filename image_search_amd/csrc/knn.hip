@@ -112,6 +112,22 @@ void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint
     const uint32_t lists = blocks * 4;
     ensure((void**)&t->d_cand, &t->cand_keys, (size_t)lists * kp, sizeof(uint64_t));
     launch_scan<Top>(t, d_q, kp, lo, t->d_cand, blocks, s);
+    if constexpr (Top::LDS_KEYS != 0) {
+        // k > 64: block-cooperative tree, 16 lists per block per level, ping-pong between d_tmp halves
+        constexpr uint32_t LPB = 16;
+        ensure((void**)&t->d_tmp, &t->tmp_keys, (size_t)2 * ((lists + LPB - 1) / LPB) * kp, sizeof(uint64_t));
+        const uint64_t* in = t->d_cand;
+        uint32_t n = lists, lvl = 0;
+        while (true) {
+            const uint32_t nb = (n + LPB - 1) / LPB;
+            uint64_t* out = nb == 1 ? keys_out : t->d_tmp + (size_t)(lvl & 1) * ((lists + LPB - 1) / LPB) * kp;
+            hipLaunchKernelGGL((knn_merge_block_kernel<Top::KP>), dim3(nb), dim3(256), 0, s, in, n, kp, LPB, out);
+            HIP_CHECK(hipGetLastError());
+            if (nb == 1) break;
+            in = out; n = nb; ++lvl;
+        }
+        return;
+    }
     // tree: <= 64 lists per block, then one block
     if (lists <= 64) {
         launch_merge<Top>(t->d_cand, lists, kp, lists, keys_out, 1, 0, 0, s);
