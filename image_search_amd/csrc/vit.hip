@@ -542,7 +542,7 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     for (int p = 0; p < parts; ++p) {
         Part& q = pt[p];
         // fp32 in both precisions: the embedding that goes to the table is not rounded to bf16 anywhere here
-        MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8)), dim3(256), 0, q.s, q.a->x, q.p1, q.p2, m->post_w, m->post_b, m->proj, q.out, (int)q.n, S, m->E, m->eps));
+        MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, q.s, q.a->x, q.p1, q.p2, m->post_w, m->post_b, m->proj, q.out, (int)q.n, S, m->E, m->eps));
         HIP_CHECK(hipGetLastError());
     }
     for (int p = 1; p < parts; ++p) {

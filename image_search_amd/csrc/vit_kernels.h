@@ -261,7 +261,11 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
         r.store(&pooled[i][0], lane);
     }
     __syncthreads();
-    for (int e = wave; e < E; e += 4) {
+    // blockIdx.y picks a slice of the E outputs (each slice redoes the 8 LayerNorms: they are cheap,
+    // the projection rows are what needs the parallelism)
+    const int ec = (E + gridDim.y - 1) / gridDim.y;
+    const int e_end = min(E, (int)(blockIdx.y + 1) * ec);
+    for (int e = blockIdx.y * ec + wave; e < e_end; e += 4) {
         const float* pr = proj + (size_t)e * D;
         float acc[IMG];
 #pragma unroll
@@ -605,12 +609,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
             for (int i = 0; i < 2; ++i)
                 wf[ks][i] = *reinterpret_cast<const bf16x8*>(base + w_off + nh * 16384 + i * 2048 + (((4 * ks + g) ^ sw) << 4));
     };
+#ifdef MI_GEMM_SETPRIO
+#define MI_PRIO(x) __builtin_amdgcn_s_setprio(x);
+#else
+#define MI_PRIO(x)
+#endif
 #define MI_QUADRANT(MH, NH)                                                                               \
+    MI_PRIO(1)                                                                                            \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
     _Pragma("unroll") for (int im = 0; im < 4; ++im)                                                      \
     _Pragma("unroll") for (int in = 0; in < 2; ++in)                                                      \
         acc[2 * NH + in][4 * MH + im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
-            wf[ks][in], xf[ks][im], acc[2 * NH + in][4 * MH + im], 0, 0, 0);
+            wf[ks][in], xf[ks][im], acc[2 * NH + in][4 * MH + im], 0, 0, 0);                               \
+    MI_PRIO(0)
 // wait mode (wave-uniform): 0 steady state, 1 first K tile after an epilogue (16 stores still
 // counted), 2 the very last K tile of this workgroup (nothing more is staged: 4, 2, 0)
 #define MI_SYNC(PH)                                                                            \

@@ -56,9 +56,9 @@ int main(int argc, char** argv) {
         const double flop = 2.0 * M * s.N * s.K;
         auto k128 = [&] { hipLaunchKernelGGL((gemm_bf16_kernel<EPI_BIAS, bf16_t>), dim3((M / 128) * (s.N / 128)), dim3(256), 65536, 0, X, W, bias, (void*)O1, s.N, s.K, s.N); };
         const int n_tiles = (int)((M / 256) * (s.N / 256));
-        auto kper = [&] { hipLaunchKernelGGL((gemm_bf16_persist_kernel<EPI_BIAS, bf16_t>), dim3(256), dim3(512), 151552, 0, X, W, bias, (void*)O2, (int)M, s.N, s.K, s.N, n_tiles, n_tiles - ((n_tiles % 256) * 4 <= 256 ? n_tiles % 256 : 0), 1); };
+        auto kper = [&] { hipLaunchKernelGGL((gemm_bf16_persist_kernel<EPI_BIAS, bf16_t>), dim3(256), dim3(512), 151552, 0, X, W, bias, (void*)O2, (int)M, s.N, s.K, s.N, n_tiles, n_tiles - ((n_tiles % 256) * 4 <= 256 ? n_tiles % 256 : 0), 0); };
         const int n_full_ = n_tiles - ((n_tiles % 256) * 4 <= 256 ? n_tiles % 256 : 0);
-        auto kper2 = [&] { hipLaunchKernelGGL((gemm_bf16_persist2_kernel<EPI_BIAS, bf16_t>), dim3(256), dim3(512), 151552, 0, X, W, bias, (void*)O2, (int)M, s.N, s.K, s.N, n_tiles, n_full_, 1); };
+        auto kper2 = [&] { hipLaunchKernelGGL((gemm_bf16_persist2_kernel<EPI_BIAS, bf16_t>), dim3(256), dim3(512), 151552, 0, X, W, bias, (void*)O2, (int)M, s.N, s.K, s.N, n_tiles, n_full_, 0); };
         float t1 = time_ms(k128, 10);
         CK(hipMemset(O2, 0, M * s.N * 2));
         float t4 = time_ms(kper, 10);
