@@ -394,10 +394,13 @@ void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out
             // Default: the plain persistent form (186 VGPRs: the other half-chunk's LayerNorm waves still
             // fit beside it; 45.7 vs 47.2 ms per 256 images).  MI_GEMM_V=2 selects the fragment-prefetch
             // form (254 VGPRs; 1-2 % faster alone, K/64 must be even).
-            static const bool v2 = std::getenv("MI_GEMM_V") && std::atoi(std::getenv("MI_GEMM_V")) == 2;
-            auto kern = (v2 && (K / 64) % 2 == 0) ? gemm_bf16_persist2_kernel<EPI, bf16_t> : gemm_bf16_persist_kernel<EPI, bf16_t>;
+            static const int ver = std::getenv("MI_GEMM_V") ? std::atoi(std::getenv("MI_GEMM_V")) : 1;
+            auto kern = (ver == 2 && (K / 64) % 2 == 0) ? gemm_bf16_persist2_kernel<EPI, bf16_t>
+                        : ver == 3                        ? gemm_bf16_pp_kernel<EPI, bf16_t>
+                                                          : gemm_bf16_persist_kernel<EPI, bf16_t>;
             static bool done = false;
             if (!done) {
+                HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
                 HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_persist2_kernel<EPI, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
                 HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<EPI, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
                 done = true;

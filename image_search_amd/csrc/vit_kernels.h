@@ -614,6 +614,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
 #else
 #define MI_PRIO(x)
 #endif
+#if defined(GEMM_ABL) && GEMM_ABL == 1
+#define MI_MODE1_CNT 5   /* no stores in the queue: 4 + bias DMA */
+#else
+#define MI_MODE1_CNT 21
+#endif
+#ifndef MI_ST_AUX
+#define MI_ST_AUX 0
+#endif
+#define MI_STR2(x) #x
+#define MI_STR(x) MI_STR2(x)
 #define MI_QUADRANT(MH, NH)                                                                               \
     MI_PRIO(1)                                                                                            \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
@@ -626,7 +636,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
 // counted), 2 the very last K tile of this workgroup (nothing more is staged: 4, 2, 0)
 #define MI_SYNC(PH)                                                                            \
     if (mode == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                             \
-    else if (mode == 1) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");                       \
+    else if (mode == 1) asm volatile("s_waitcnt vmcnt(" MI_STR(MI_MODE1_CNT) ")" ::: "memory");     \
     else if (PH == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                          \
     else if (PH == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                          \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
@@ -679,12 +689,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
         }
         if (!last_kt) { ++kt; continue; }
 
+#if defined(GEMM_ABL) && GEMM_ABL == 2  // timing only: no epilogue at all
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+        if (!has_next) break;
+        tile = next; cur = nxt; xs = s_x; ws = s_w; kt = 0; after_epilogue = false;
+        continue;
+#endif
         // epilogue: each 16-row m-tile of the wave's slab goes through a wave-private LDS patch
         // (16 rows x 144 B, beyond the two staging buffers) so that the global stores are whole
         // 128-byte row segments, 16 bytes per lane: exactly 16 stores per lane, left in flight.
         __builtin_amdgcn_sched_barrier(0);
         const int n0 = cur.tn * 256;
+#if defined(GEMM_ABL) && GEMM_ABL == 3  // timing only: every tile stored over tile (lb % 8, 0): L2-resident
+        const uint32_t o_tile = ((uint32_t)(lb & 7) * 256u * (uint32_t)ldo + 0u * (uint32_t)n0) * 2u;
+#else
         const uint32_t o_tile = ((uint32_t)cur.tm * 256u * (uint32_t)ldo + (uint32_t)n0) * 2u;
+#endif
         v4f bv[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) bv[ni] = *reinterpret_cast<const v4f*>(bias_lds + (ni * 16 + 4 * g) * 4);
@@ -714,7 +737,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
                 const int row = j * 8 + (lane >> 3);
                 const v4u d = *reinterpret_cast<const v4u*>(patch + row * 144 + (lane & 7) * 16);
                 const uint32_t so = o_tile + (uint32_t)(mi * 16 + j * 8) * (uint32_t)ldo * 2u;
-                __builtin_amdgcn_raw_buffer_store_b128(d, orr, o_lane, so, 0);
+#if defined(GEMM_ABL) && GEMM_ABL == 1  // timing only: no output stores
+                asm volatile("" ::"v"(d), "s"(so));
+#else
+                __builtin_amdgcn_raw_buffer_store_b128(d, orr, o_lane, so, MI_ST_AUX);
+#endif
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -789,6 +816,280 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
 #undef MI_QUADRANT
 #undef MI_SYNC
 #undef MI_STAGE
+}
+
+// ------------------------------------------------------------------ bf16 GEMM, persistent, two staggered wave groups
+// Same tile (256 x 256 x 64), LDS image and epilogue as gemm_bf16_persist_kernel, other schedule:
+// the two wave rows (waves 0-3 / 4-7: one wave of each per SIMD) run ONE BARRIER APART, so that in
+// every barrier interval one group issues its 16 MFMAs while the other fetches its next fragments
+// from LDS and issues the next half-tile's LDS-DMA -- the LDS latency and bandwidth that the
+// one-barrier form pays in front of every MFMA cluster are hidden behind the partner group.
+//   phase p of a wave:  ds_read(fragments of p) ; stage one half-tile ; s_waitcnt vmcnt ; BARRIER ;
+//                       16 MFMA ; BARRIER                  (group 1 enters one barrier late)
+//   half-tile stream:   XH0 WH0 WH1 XH1 of K tile u are issued in phases 4u-6 .. 4u-3 and read in
+//                       4u, 4u, 4u+1, 4u+2 (>= 5 phases later); a slot is refilled >= 2 phases after
+//                       its last read; each phase waits for everything issued <= 4 phases ago
+//                       (vmcnt(8)) and the data is read one phase after that wait.
+//   W fragments of both n-halves stay in registers (20 ds_read_b128 per K tile, 208 VGPRs).
+//   epilogue of tile T:  inside phase 0 of tile T+1 for both groups in the same barrier interval
+//                       (group 1: before its reads; group 0: between its barrier and its MFMAs),
+//                       17 more ops in the queue for the next 4 waits (vmcnt(25)).
+template <int EPI, typename TO>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ X,
+                                                              const bf16_t* __restrict__ W,
+                                                              const float* __restrict__ bias,
+                                                              void* __restrict__ out, int M, int N, int K, int ldo,
+                                                              int n_tiles, int n_full, int /*unused*/) {
+    static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU, "the persistent form stores bf16 with bias");
+    static_assert(sizeof(TO) == 2, "bf16 output");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 128 KiB staging + 18 KiB patches + 2 KiB bias
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, g = lane >> 4, l15 = lane & 15;
+    const int nt = N / 256;
+    const int G = gridDim.x;
+    const int lb = (int)xcd_remap(blockIdx.x, G);
+
+    const uint32_t Kb = (uint32_t)K * 2;
+    const rsrc_t xr = make_rsrc(X, (uint32_t)M * Kb);
+    const rsrc_t wr = make_rsrc(W, (uint32_t)N * Kb);
+    const rsrc_t orr = make_rsrc(out, (uint32_t)M * (uint32_t)ldo * (uint32_t)sizeof(TO));
+    const rsrc_t br = make_rsrc(bias, (uint32_t)N * 4u);
+    const int rr = lane >> 3, p = lane & 7;
+    const uint32_t x_lane = (uint32_t)rr * Kb + 16 * (p ^ rr);
+    const uint32_t x_wave = (uint32_t)(128 * (wave >> 2) + 16 * (wave & 3)) * Kb;
+    const uint32_t w_wave = (uint32_t)(64 * (wave >> 1) + 16 * (wave & 1)) * Kb;
+    // piece j of a K tile: 0 = XH0, 1 = WH0, 2 = WH1, 3 = XH1
+    auto stage_half = [&](int buf, uint32_t xs, uint32_t ws, int kt, int j) {
+        const bool is_x = (j == 0 || j == 3);
+        const int h = (j >= 2) ? 1 : 0;
+        unsigned char* dst = smem + buf * 65536 + (is_x ? 0 : 32768) + h * 16384 + wave * 2048;
+        const uint32_t so = (is_x ? xs + x_wave + 64u * h * Kb : ws + w_wave + 32u * h * Kb) + (uint32_t)kt * 128u;
+        glds16_buf(is_x ? xr : wr, x_lane, so, dst);
+        glds16_buf(is_x ? xr : wr, x_lane, so + 8u * Kb, dst + 1024);
+    };
+    unsigned char* bias_lds = smem + 131072 + 18432 + wave * 256;
+    auto stage_bias = [&](int tn) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (__attribute__((address_space(3))) void*)bias_lds, 4,
+                                                 (uint32_t)lane * 4u, (uint32_t)(tn * 256 + wn * 64) * 4u, 0, 0);
+    };
+
+    const int sw = lane & 7;
+    const int x_off = (wm * 64 + l15) * 128;
+    const int w_off = 32768 + (wn * 32 + l15) * 128;
+    bf16x8 xf[2][4], w0f[2][2], w1f[2][2];
+    v4f acc[4][8];
+    auto load_x = [&](const unsigned char* base, int mh) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xf[ks][i] = *reinterpret_cast<const bf16x8*>(base + x_off + mh * 16384 + i * 2048 + (((4 * ks + g) ^ sw) << 4));
+    };
+    auto load_w = [&](bf16x8 (&wf)[2][2], const unsigned char* base, int nh) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                wf[ks][i] = *reinterpret_cast<const bf16x8*>(base + w_off + nh * 16384 + i * 2048 + (((4 * ks + g) ^ sw) << 4));
+    };
+#define PP_BAR { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); }
+#define PP_QUADRANT(MH, NH, WF)                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
+    _Pragma("unroll") for (int im = 0; im < 4; ++im)                                                      \
+    _Pragma("unroll") for (int in = 0; in < 2; ++in)                                                      \
+        acc[2 * NH + in][4 * MH + im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
+            WF[ks][in], xf[ks][im], acc[2 * NH + in][4 * MH + im], 0, 0, 0);                               \
+    __builtin_amdgcn_s_setprio(0);
+
+    // position in the flattened (tile, K tile) stream of this workgroup
+    struct Pos { uint32_t xs, ws; int kt, tile, tm, tn; bool ok; };
+    const int nk = K / 64;
+    auto pos_of_tile = [&](int t) {
+        Pos q;
+        q.tile = t; q.kt = 0; q.ok = t < n_full;
+        q.tm = t / nt; q.tn = t - q.tm * nt;
+        q.xs = (uint32_t)q.tm * 256u * Kb; q.ws = (uint32_t)q.tn * 256u * Kb;
+        return q;
+    };
+    auto advance = [&](const Pos& a) {
+        if (!a.ok) return a;
+        if (a.kt + 1 < nk) { Pos q = a; q.kt = a.kt + 1; return q; }
+        return pos_of_tile(a.tile + G);
+    };
+    const uint32_t o_lane = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
+    unsigned char* patch = smem + 131072 + wave * 2304;
+    // bias + activation + bf16 + 128-byte row segments through the wave's LDS patch; clears acc
+    auto epilogue = [&](int tm, int tn) {
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t o_tile = ((uint32_t)tm * 256u * (uint32_t)ldo + (uint32_t)tn * 256u) * 2u;
+        v4f bv[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bv[ni] = *reinterpret_cast<const v4f*>(bias_lds + (ni * 16 + 4 * g) * 4);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                v4f v = acc[ni][mi] + bv[ni];
+                acc[ni][mi] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                if constexpr (EPI == EPI_BIAS_QGELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = quick_gelu<true>(v[c]);
+                }
+                v2u pk;
+                pk.x = pack2bf(v[0], v[1]);
+                pk.y = pack2bf(v[2], v[3]);
+                *reinterpret_cast<v2u*>(patch + l15 * 144 + (ni * 16 + 4 * g) * 2) = pk;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = j * 8 + (lane >> 3);
+                const v4u d = *reinterpret_cast<const v4u*>(patch + row * 144 + (lane & 7) * 16);
+                const uint32_t so = o_tile + (uint32_t)(mi * 16 + j * 8) * (uint32_t)ldo * 2u;
+                __builtin_amdgcn_raw_buffer_store_b128(d, orr, o_lane, so, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[a][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+
+    Pos C = pos_of_tile(lb);
+    if (C.ok) {
+        // prologue = the staging of phases -6 .. -1: K tile 0 whole, XH0 and WH0 of K tile 1
+        Pos A = advance(C);  // nk >= 2: same tile
+        stage_bias(C.tn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stage_half(0, C.xs, C.ws, 0, j);
+        stage_half(1, A.xs, A.ws, A.kt, 0);
+        stage_half(1, A.xs, A.ws, A.kt, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        PP_BAR
+        if (wm == 1) PP_BAR // group 1 runs one barrier behind from here on
+        int b = 0, relax = 0;
+        bool epi = false;
+        int e_tm = 0, e_tn = 0;
+// one phase.  READS: this phase's fragment loads; (PK, PB, PJ): the half-tile it stages
+#define PP_WAIT(PK)                                                                   \
+    if (!(PK).ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    \
+    else if (relax > 0) { asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); --relax; } \
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#define PP_STAGE(PK, PB, PJ) if ((PK).ok) stage_half(PB, (PK).xs, (PK).ws, (PK).kt, PJ);
+        for (;;) {
+            const Pos B = advance(A);
+            const unsigned char* base = smem + b * 65536;
+            // ---- phase 0: X half 0, W half 0 -> quadrant (0,0); stages WH1 of the next K tile
+            if (!epi) {
+                load_w(w0f, base, 0); __builtin_amdgcn_sched_barrier(0); load_x(base, 0);
+                PP_STAGE(A, b ^ 1, 2) PP_WAIT(A)
+                PP_BAR
+            } else {
+                // both groups run the previous tile's epilogue in the SAME barrier interval: group 1
+                // in front of its barrier, group 0 behind its own (which is the same instance)
+                PP_STAGE(A, b ^ 1, 2) PP_WAIT(A)
+                if (wm == 0) PP_BAR
+                epilogue(e_tm, e_tn);
+                stage_bias(C.tn);
+                relax = 4;
+                load_w(w0f, base, 0); __builtin_amdgcn_sched_barrier(0); load_x(base, 0);
+                if (wm == 1) PP_BAR
+            }
+            epi = false;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_QUADRANT(0, 0, w0f)
+            PP_BAR
+            // ---- phase 1: W half 1 -> quadrant (0,1); stages XH1 of the next K tile
+            load_w(w1f, base, 1);
+            PP_STAGE(A, b ^ 1, 3) PP_WAIT(A)
+            PP_BAR
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_QUADRANT(0, 1, w1f)
+            PP_BAR
+            // ---- phase 2: X half 1 -> quadrant (1,1); stages XH0 of the K tile after next
+            load_x(base, 1);
+            PP_STAGE(B, b, 0) PP_WAIT(B)
+            PP_BAR
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_QUADRANT(1, 1, w1f)
+            PP_BAR
+            // ---- phase 3: nothing to read -> quadrant (1,0); stages WH0 of the K tile after next
+            PP_STAGE(B, b, 1) PP_WAIT(B)
+            PP_BAR
+            PP_QUADRANT(1, 0, w0f)
+            PP_BAR
+            b ^= 1;
+            if (C.kt == nk - 1) { epi = true; e_tm = C.tm; e_tn = C.tn; }
+            if (!A.ok) break;
+            C = A;
+            A = B;
+        }
+        // last tile of this workgroup: group 0 first (its extra barrier is group 1's last one)
+        if (wm == 0) { epilogue(e_tm, e_tn); PP_BAR }
+        else epilogue(e_tm, e_tn);
+#undef PP_WAIT
+#undef PP_STAGE
+    }
+
+    // ---- the last, partial round as quadrant tasks (as in gemm_bf16_persist_kernel)
+    const int n_tasks = (n_tiles - n_full) * 4;
+    for (int task = lb; task < n_tasks; task += G) {
+        const int t = n_full + (task >> 2), mh = (task >> 1) & 1, nh = task & 1;
+        const int ttm = t / nt, ttn = t - ttm * nt;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_BAR
+        const uint32_t txs = (uint32_t)ttm * 256u * Kb + 64u * mh * Kb, tws = (uint32_t)ttn * 256u * Kb + 32u * nh * Kb;
+        stage_bias(ttn);
+        stage_half(0, txs, tws, 0, 0); stage_half(0, txs, tws, 0, 1);
+        if (nk > 1) { stage_half(1, txs, tws, 1, 0); stage_half(1, txs, tws, 1, 1); }
+        for (int kq = 0; kq < nk; ++kq) {
+            if (kq + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PP_BAR
+            const unsigned char* base = smem + (kq & 1) * 65536;
+            load_x(base, 0); load_w(w0f, base, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_BAR  // every wave has its fragments: the buffer may be refilled
+            if (kq + 2 < nk) { stage_half(kq & 1, txs, tws, kq + 2, 0); stage_half(kq & 1, txs, tws, kq + 2, 1); }
+            PP_QUADRANT(0, 0, w0f)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        v4f bq[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bq[ni] = *reinterpret_cast<const v4f*>(bias_lds + (32 * nh + ni * 16 + 4 * g) * 4);
+        const uint32_t q_tile = ((uint32_t)ttm * 256u * (uint32_t)ldo + (uint32_t)(ttn * 256)) * 2u;
+        const uint32_t q_lane = ((uint32_t)(wm * 128 + 64 * mh + (lane >> 2)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 32 * nh + 8 * (lane & 3))) * 2u;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                v4f v = acc[ni][mi] + bq[ni];
+                acc[ni][mi] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                if constexpr (EPI == EPI_BIAS_QGELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = quick_gelu<true>(v[c]);
+                }
+                v2u pk;
+                pk.x = pack2bf(v[0], v[1]);
+                pk.y = pack2bf(v[2], v[3]);
+                *reinterpret_cast<v2u*>(patch + l15 * 144 + (ni * 16 + 4 * g) * 2) = pk;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const v4u d = *reinterpret_cast<const v4u*>(patch + (lane >> 2) * 144 + (lane & 3) * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(d, orr, q_lane, q_tile + (uint32_t)(mi * 16) * (uint32_t)ldo * 2u, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef PP_QUADRANT
+#undef PP_BAR
 }
 
 // ------------------------------------------------------------------ bf16 GEMM, persistent, fragment prefetch

@@ -51,14 +51,14 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(fill_bf16, 2048, 256, 0, 0, W, (size_t)4096 * 4096, 7, 0.05f);
     CK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI_BIAS, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     CK(hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<EPI_BIAS, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 151552));
-    CK(hipFuncSetAttribute((const void*)gemm_bf16_persist2_kernel<EPI_BIAS, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 151552));
+    CK(hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI_BIAS, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 151552));
     for (auto& s : shapes) {
         const double flop = 2.0 * M * s.N * s.K;
         auto k128 = [&] { hipLaunchKernelGGL((gemm_bf16_kernel<EPI_BIAS, bf16_t>), dim3((M / 128) * (s.N / 128)), dim3(256), 65536, 0, X, W, bias, (void*)O1, s.N, s.K, s.N); };
         const int n_tiles = (int)((M / 256) * (s.N / 256));
         auto kper = [&] { hipLaunchKernelGGL((gemm_bf16_persist_kernel<EPI_BIAS, bf16_t>), dim3(256), dim3(512), 151552, 0, X, W, bias, (void*)O2, (int)M, s.N, s.K, s.N, n_tiles, n_tiles - ((n_tiles % 256) * 4 <= 256 ? n_tiles % 256 : 0), 0); };
         const int n_full_ = n_tiles - ((n_tiles % 256) * 4 <= 256 ? n_tiles % 256 : 0);
-        auto kper2 = [&] { hipLaunchKernelGGL((gemm_bf16_persist2_kernel<EPI_BIAS, bf16_t>), dim3(256), dim3(512), 151552, 0, X, W, bias, (void*)O2, (int)M, s.N, s.K, s.N, n_tiles, n_full_, 0); };
+        auto kper2 = [&] { hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BIAS, bf16_t>), dim3(256), dim3(512), 151552, 0, X, W, bias, (void*)O2, (int)M, s.N, s.K, s.N, n_tiles, n_full_, 0); };
         float t1 = time_ms(k128, 10);
         CK(hipMemset(O2, 0, M * s.N * 2));
         float t4 = time_ms(kper, 10);
@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
             if (h[0]) printf("   mismatches %llu first at row %llu col %llu (tile m %llu n %llu)\n", h[0], h[1] / s.N, h[1] % s.N, h[1] / s.N / 256, (h[1] % s.N) / 256);
             CK(hipFree(c));
         }
-        printf("%s N=%d K=%d: 128^2 %.3f ms %.0f TF | persist %.3f ms %.0f TF | persist2 %.3f ms %.0f TF | maxdiff(persist2 vs 128) %.4g\n", s.name, s.N, s.K, t1, flop / t1 / 1e9, t4, flop / t4 / 1e9, t5, flop / t5 / 1e9, md);
+        printf("%s N=%d K=%d: 128^2 %.3f ms %.0f TF | persist %.3f ms %.0f TF | pp %.3f ms %.0f TF | maxdiff(pp vs 128) %.4g\n", s.name, s.N, s.K, t1, flop / t1 / 1e9, t4, flop / t4 / 1e9, t5, flop / t5 / 1e9, md);
     }
     return 0;
 }
