@@ -207,7 +207,7 @@ def main():
             "vit": {"images_per_sec": round(world * args.batch / (ms_vit * 1e-3), 1), "ms_per_batch": round(ms_vit, 3)},
             "knn": {"queries_per_sec": round(1e3 / ms_knn, 2), "ms_per_query": round(ms_knn, 4),
                     "rows_scanned_per_sec": round(world * args.rows / (ms_knn * 1e-3), 0), "dtype": "f32"},
-            "roofline": {"bound": "mfma", "kernel": "ViT-L/14 forward (gemm_bf16_persist_kernel x 96 + attention + LayerNorm, two half-chunk streams)",
+            "roofline": {"bound": "mfma", "kernel": "ViT-L/14 forward (gemm_bf16_pp_kernel x 96 + attention + LayerNorm, two half-chunk streams)",
                          "achieved": round(vit_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(vit_tflops / PEAK_BF16_TFLOPS, 4),
                          "traffic": pmc.get("vit_hbm_bytes") if traffic_ok else None},
