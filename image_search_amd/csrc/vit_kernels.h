@@ -821,19 +821,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t*
 // ------------------------------------------------------------------ bf16 GEMM, persistent, two staggered wave groups
 // Same tile (256 x 256 x 64), LDS image and epilogue as gemm_bf16_persist_kernel, other schedule:
 // the two wave rows (waves 0-3 / 4-7: one wave of each per SIMD) run ONE BARRIER APART, so that in
-// every barrier interval one group issues its 16 MFMAs while the other fetches its next fragments
-// from LDS and issues the next half-tile's LDS-DMA -- the LDS latency and bandwidth that the
-// one-barrier form pays in front of every MFMA cluster are hidden behind the partner group.
-//   phase p of a wave:  ds_read(fragments of p) ; stage one half-tile ; s_waitcnt vmcnt ; BARRIER ;
-//                       16 MFMA ; BARRIER                  (group 1 enters one barrier late)
-//   half-tile stream:   XH0 WH0 WH1 XH1 of K tile u are issued in phases 4u-6 .. 4u-3 and read in
-//                       4u, 4u, 4u+1, 4u+2 (>= 5 phases later); a slot is refilled >= 2 phases after
-//                       its last read; each phase waits for everything issued <= 4 phases ago
-//                       (vmcnt(8)) and the data is read one phase after that wait.
-//   W fragments of both n-halves stay in registers (20 ds_read_b128 per K tile, 208 VGPRs).
-//   epilogue of tile T:  inside phase 0 of tile T+1 for both groups in the same barrier interval
-//                       (group 1: before its reads; group 0: between its barrier and its MFMAs),
-//                       17 more ops in the queue for the next 4 waits (vmcnt(25)).
+// every barrier interval one group issues MFMAs while the other fetches its next fragments from LDS
+// and issues the next half-tiles' LDS-DMA -- the LDS latency and bandwidth that the one-barrier form
+// pays in front of every MFMA cluster are hidden behind the partner group.
+//   a phase is a HALF K tile (two quadrants, 32 MFMAs):
+//     ds_read(fragments) ; lgkmcnt(0) ; stage half-tiles ; s_waitcnt vmcnt ; BARRIER ; 32 MFMA ; BARRIER
+//   phase A of K tile t: reads XH0 WH0 WH1 (16 ds_read_b128) -> quadrants (0,0) (0,1); stages XH1(t+1)
+//   phase B of K tile t: reads XH1 (8)                        -> quadrants (1,1) (1,0); stages XH0 WH0 WH1(t+2)
+//   (group 1 enters one barrier late; W fragments of both n-halves stay in registers: 24 reads per
+//   K tile, 214 VGPRs.)  The fragment reads are retired BEFORE the phase's first barrier, so a slot
+//   may be refilled one phase after its last read; every half-tile is read 3 phases after it was
+//   issued and one phase after the counted wait (vmcnt(8): the issues of this and the previous
+//   phase) that retires it -- the wait of phase q is in front of q's first barrier, the read behind
+//   q's second one, which both groups have passed only after both have waited.
+//   epilogue of tile T: inside phase A of tile T+1, for both groups in the same barrier interval
+//   (group 1 in front of its barrier, group 0 behind its own = the same instance); its 16 stores and
+//   the bias DMA stay in the queue for the next two waits (vmcnt(25)).
+//   A four-phase form (16 MFMAs per barrier interval, 8 barriers per K tile) measured 2-3 % slower.
 template <int EPI, typename TO>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ X,
                                                               const bf16_t* __restrict__ W,
@@ -963,13 +967,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
 
     Pos C = pos_of_tile(lb);
     if (C.ok) {
-        // prologue = the staging of phases -6 .. -1: K tile 0 whole, XH0 and WH0 of K tile 1
+        // prologue = the staging of phases -3 .. -1: K tile 0 whole, XH0 WH0 WH1 of K tile 1
         Pos A = advance(C);  // nk >= 2: same tile
         stage_bias(C.tn);
 #pragma unroll
         for (int j = 0; j < 4; ++j) stage_half(0, C.xs, C.ws, 0, j);
-        stage_half(1, A.xs, A.ws, A.kt, 0);
-        stage_half(1, A.xs, A.ws, A.kt, 1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) stage_half(1, A.xs, A.ws, A.kt, j);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         PP_BAR
         if (wm == 1) PP_BAR // group 1 runs one barrier behind from here on
@@ -985,43 +989,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
         for (;;) {
             const Pos B = advance(A);
             const unsigned char* base = smem + b * 65536;
-            // ---- phase 0: X half 0, W half 0 -> quadrant (0,0); stages WH1 of the next K tile
+            // ---- phase A: X half 0, both W halves -> quadrants (0,0) (0,1); stages XH1 of the next K tile
             if (!epi) {
-                load_w(w0f, base, 0); __builtin_amdgcn_sched_barrier(0); load_x(base, 0);
-                PP_STAGE(A, b ^ 1, 2) PP_WAIT(A)
+                load_w(w0f, base, 0); load_w(w1f, base, 1); __builtin_amdgcn_sched_barrier(0); load_x(base, 0);
+                PP_STAGE(A, b ^ 1, 3) PP_WAIT(A)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PP_BAR
             } else {
                 // both groups run the previous tile's epilogue in the SAME barrier interval: group 1
                 // in front of its barrier, group 0 behind its own (which is the same instance)
-                PP_STAGE(A, b ^ 1, 2) PP_WAIT(A)
+                PP_STAGE(A, b ^ 1, 3) PP_WAIT(A)
                 if (wm == 0) PP_BAR
                 epilogue(e_tm, e_tn);
                 stage_bias(C.tn);
-                relax = 4;
-                load_w(w0f, base, 0); __builtin_amdgcn_sched_barrier(0); load_x(base, 0);
+                relax = 2;
+                load_w(w0f, base, 0); load_w(w1f, base, 1); __builtin_amdgcn_sched_barrier(0); load_x(base, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (wm == 1) PP_BAR
             }
             epi = false;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_QUADRANT(0, 0, w0f)
-            PP_BAR
-            // ---- phase 1: W half 1 -> quadrant (0,1); stages XH1 of the next K tile
-            load_w(w1f, base, 1);
-            PP_STAGE(A, b ^ 1, 3) PP_WAIT(A)
-            PP_BAR
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_QUADRANT(0, 1, w1f)
             PP_BAR
-            // ---- phase 2: X half 1 -> quadrant (1,1); stages XH0 of the K tile after next
+            // ---- phase B: X half 1 -> quadrants (1,1) (1,0); stages XH0 WH0 WH1 of the K tile after next
             load_x(base, 1);
-            PP_STAGE(B, b, 0) PP_WAIT(B)
-            PP_BAR
+            PP_STAGE(B, b, 0) PP_STAGE(B, b, 1) PP_STAGE(B, b, 2) PP_WAIT(B)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_BAR
             PP_QUADRANT(1, 1, w1f)
-            PP_BAR
-            // ---- phase 3: nothing to read -> quadrant (1,0); stages WH0 of the K tile after next
-            PP_STAGE(B, b, 1) PP_WAIT(B)
-            PP_BAR
             PP_QUADRANT(1, 0, w0f)
             PP_BAR
             b ^= 1;

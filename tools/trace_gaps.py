@@ -29,3 +29,20 @@ for q, L in byq.items():
 agg = collections.defaultdict(lambda: [0, 0])
 for s, e, n, _ in fw: agg[n][0] += 1; agg[n][1] += e - s
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]: print(f"  {n:42s} x{c:4d}  {t/1e6:8.3f} ms  avg {t/c/1e3:8.1f} us")
+
+# ---- which kinds of kernel are in flight together (sweep line over the forward)
+def kind(n):
+    return "gemm" if "gemm" in n else "attn" if "attn" in n else "ln" if ("ln_kernel" in n or "embed_ln" in n) else "other"
+pts = []
+for s, e, n, _ in fw:
+    pts.append((s, 1, kind(n))); pts.append((e, -1, kind(n)))
+pts.sort()
+live = collections.Counter(); state_t = collections.Counter(); last = pts[0][0]
+for t, d, k in pts:
+    key = "+".join(f"{kk}{live[kk] if live[kk] > 1 else ''}" for kk in sorted(live) if live[kk] > 0) or "idle"
+    state_t[key] += t - last
+    last = t
+    live[k] += d
+print("in flight together:")
+for k, t in sorted(state_t.items(), key=lambda kv: -kv[1]):
+    if t > 0: print(f"  {k:24s} {t/1e6:8.3f} ms")
