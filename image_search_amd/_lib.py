@@ -28,6 +28,11 @@ SYMBOLS = {
     "mi_clip_embed_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "mi_clip_embed_rgb8": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "mi_preprocess_rgb8": (ctypes.c_int, [c_vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, c_vp]),
+    "mi_resize_catmullrom_rgb8": (ctypes.c_int, [ctypes.c_int, c_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                                 ctypes.c_uint32, c_vp]),
+    "mi_image_prepare_resnet": (ctypes.c_int, [ctypes.c_int, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp]),
+    "mi_clip_embed_images": (ctypes.c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(ctypes.c_uint32),
+                                            ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t, c_vp]),
     "mi_knn_create": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "mi_knn_free": (None, [c_vp]),
     "mi_knn_set_base": (ctypes.c_int, [c_vp, ctypes.c_uint64]),

@@ -3,8 +3,8 @@
 `clip_vit_large_patch14.Model.from_file(path, device)` and `.forward(tensor)` keep
 the names and argument meaning of the generated Burn module the reference calls
 (/root/reference/clip/src/lib.rs:2-7, call sites server/src/clip.rs:46-48, :118);
-`image_prepare_resnet` is server/src/clip.rs:153-175 minus the resize (the `image`
-crate's CatmullRom `resize_exact` is upstream of this path: SURVEY.md §8f rank 2).
+`image_prepare_resnet` is server/src/clip.rs:153-175: the `image` crate's CatmullRom
+`resize_exact` (image 0.25.8) and the ImageNet normalisation, both on the device.
 """
 from __future__ import annotations
 
@@ -30,9 +30,26 @@ def is_image_path(path: str) -> bool:
     return name[dot + 1:].lower() in EXTENSIONS
 
 
-def image_prepare_resnet(rgb8_hwc: np.ndarray) -> np.ndarray:
-    """RGB8 HWC (already 224x224) -> CHW f32, ImageNet mean/std (clip.rs:158-172)."""
+def resize_exact(rgb8_hwc: np.ndarray, nwidth: int, nheight: int, device: int = 0) -> np.ndarray:
+    """`DynamicImage::resize_exact(nwidth, nheight, FilterType::CatmullRom)` for an RGB8 image
+    [H,W,3] -> [nheight,nwidth,3] u8, on GPU `device` (clip.rs:154)."""
     a = np.ascontiguousarray(rgb8_hwc, np.uint8)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError(f"expected [H,W,3] u8, got {a.shape}")
+    out = np.empty((nheight, nwidth, 3), np.uint8)
+    check(lib().mi_resize_catmullrom_rgb8(device, a.ctypes.data, a.shape[1], a.shape[0], nwidth, nheight, out.ctypes.data))
+    return out
+
+
+def image_prepare_resnet(rgb8_hwc: np.ndarray, device: int = 0) -> np.ndarray:
+    """clip.rs:153-175.  One RGB8 image [H,W,3] of any size -> CHW f32 [3,224,224] (resize +
+    normalisation on GPU `device`); a batch [n,224,224,3] already at model resolution keeps the
+    host arithmetic of clip.rs:158-172."""
+    a = np.ascontiguousarray(rgb8_hwc, np.uint8)
+    if a.ndim == 3 and a.shape[:2] != (224, 224):
+        out = np.empty((3, 224, 224), np.float32)
+        check(lib().mi_image_prepare_resnet(device, a.ctypes.data, a.shape[1], a.shape[0], out.ctypes.data))
+        return out
     single = a.ndim == 3
     a = a.reshape((-1,) + a.shape[-3:])
     n, h, w, _ = a.shape
@@ -78,6 +95,21 @@ class Model:
             raise ValueError(f"expected [n,{self.image},{self.image},3] u8, got {a.shape}")
         out = np.empty((a.shape[0], self.proj), np.float32)
         check(lib().mi_clip_embed_rgb8(self._h, a.ctypes.data, a.shape[0], out.ctypes.data))
+        return out
+
+    def forward_images(self, images) -> np.ndarray:
+        """One chunk of the scan loop (clip.rs:92-124): decoded RGB8 images [H_i,W_i,3] of any
+        sizes -> [n,proj] f32; resize, normalisation and the tower all on the device."""
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        for im in imgs:
+            if im.ndim != 3 or im.shape[2] != 3:
+                raise ValueError(f"expected [H,W,3] u8, got {im.shape}")
+        n = len(imgs)
+        out = np.empty((n, self.proj), np.float32)
+        ptrs = (c_vp * max(n, 1))(*[im.ctypes.data for im in imgs])
+        ws = (ctypes.c_uint32 * max(n, 1))(*[im.shape[1] for im in imgs])
+        hs = (ctypes.c_uint32 * max(n, 1))(*[im.shape[0] for im in imgs])
+        check(lib().mi_clip_embed_images(self._h, ptrs, ws, hs, n, out.ctypes.data))
         return out
 
     def forward_device(self, d_nchw: int, n: int, d_out: int, stream: int = 0):

@@ -13,6 +13,7 @@
 
 #include "common.h"
 #include "../../include/mi355clip_ops.h"
+#include "preprocess_kernels.h"
 #include "vit_kernels.h"
 
 using namespace mi;
@@ -205,6 +206,12 @@ struct mi_clip {
     int parts = 2;  // MI_CLIP_PARTS: sub-chunks run as independent streams
     int n_cu = 256;
     uint8_t* d_rgb = nullptr;
+    // mi_clip_embed_images: two upload buffers for decoded images, the resize intermediate, a copy stream
+    uint8_t* d_img_src[2] = {nullptr, nullptr};
+    float* d_img_tmp = nullptr;
+    size_t img_src_cap = 0, img_tmp_cap = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
     hipStream_t stream = nullptr;
     size_t max_batch = 256;
     std::mutex mu;
@@ -561,6 +568,13 @@ void free_model(mi_clip* m) {
     for (auto& a : m->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     for (auto& e : m->ev_join) if (e) (void)hipEventDestroy(e);
+    if (m->copy_stream) { (void)hipStreamSynchronize(m->copy_stream); (void)hipStreamDestroy(m->copy_stream); }
+    for (int b = 0; b < 2; ++b) {
+        if (m->ev_up[b]) (void)hipEventDestroy(m->ev_up[b]);
+        if (m->ev_used[b]) (void)hipEventDestroy(m->ev_used[b]);
+        if (m->d_img_src[b]) (void)hipFree(m->d_img_src[b]);
+    }
+    if (m->d_img_tmp) (void)hipFree(m->d_img_tmp);
     for (void* p : m->allocs) (void)hipFree(p);
     for (void* p : m->ws) (void)hipFree(p);
     delete m;
@@ -663,6 +677,71 @@ int mi_clip_embed_rgb8(mi_clip* m, const uint8_t* rgb8, size_t n, float* out) {
             HIP_CHECK(hipGetLastError());
             forward(m, m->d_in, c, m->d_out, m->stream);
             HIP_CHECK(hipMemcpyAsync(out + i * m->E, m->d_out, c * m->E * 4, hipMemcpyDeviceToHost, m->stream));
+            HIP_CHECK(hipStreamSynchronize(m->stream));
+        }
+    });
+}
+
+// The whole of server/src/clip.rs:92-124 for one chunk: decoded RGB8 images of any size ->
+// CatmullRom resize + ImageNet normalisation on the device, straight into the tower's input.
+int mi_clip_embed_images(mi_clip* m, const uint8_t* const* rgb8, const uint32_t* widths, const uint32_t* heights,
+                         size_t n, float* out) {
+    return guarded([&] {
+        if (!m) fail(MI_ERR_INVALID, "null model handle");
+        if (n == 0) return;
+        if (!rgb8 || !widths || !heights || !out) fail(MI_ERR_INVALID, "null buffer");
+        size_t max_src = 0, max_tmp = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (!rgb8[i]) fail(MI_ERR_INVALID, "null image %zu", i);
+            const char* why = nullptr;
+            if (!resize_supported(widths[i], heights[i], (uint32_t)m->image, (uint32_t)m->image, &why))
+                fail(MI_ERR_UNSUPPORTED, "image %zu (%ux%u): %s", i, widths[i], heights[i], why);
+            max_src = std::max(max_src, (size_t)widths[i] * heights[i] * 3);
+            max_tmp = std::max(max_tmp, (size_t)m->image * widths[i] * 3 * 4);
+        }
+        std::lock_guard<std::mutex> l(m->mu);
+        DeviceGuard g(m->device);
+        const size_t plane = (size_t)m->image * m->image, px = plane * 3;
+        const size_t chunk = std::min(n, m->max_batch);
+        ensure_workspace(m, chunk);
+        // two source buffers: the upload of image i+1 overlaps the resize of image i
+        if (max_src > m->img_src_cap) {
+            for (int b = 0; b < 2; ++b) {
+                if (m->d_img_src[b]) HIP_CHECK(hipFree(m->d_img_src[b]));
+                m->d_img_src[b] = nullptr;
+                HIP_CHECK(hipMalloc((void**)&m->d_img_src[b], max_src));
+            }
+            m->img_src_cap = max_src;
+        }
+        if (max_tmp > m->img_tmp_cap) {
+            if (m->d_img_tmp) HIP_CHECK(hipFree(m->d_img_tmp));
+            m->d_img_tmp = nullptr;
+            HIP_CHECK(hipMalloc((void**)&m->d_img_tmp, max_tmp));
+            m->img_tmp_cap = max_tmp;
+        }
+        if (!m->copy_stream) {
+            HIP_CHECK(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+            for (int b = 0; b < 2; ++b) {
+                HIP_CHECK(hipEventCreateWithFlags(&m->ev_up[b], hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&m->ev_used[b], hipEventDisableTiming));
+            }
+        }
+        for (size_t i0 = 0; i0 < n; i0 += chunk) {
+            const size_t c = std::min(chunk, n - i0);
+            for (size_t j = 0; j < c; ++j) {
+                const size_t i = i0 + j;
+                const int b = (int)(i & 1);
+                if (i >= 2) HIP_CHECK(hipStreamWaitEvent(m->copy_stream, m->ev_used[b], 0));  // buffer b consumed
+                HIP_CHECK(hipMemcpyAsync(m->d_img_src[b], rgb8[i], (size_t)widths[i] * heights[i] * 3, hipMemcpyHostToDevice, m->copy_stream));
+                HIP_CHECK(hipEventRecord(m->ev_up[b], m->copy_stream));
+                HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_up[b], 0));
+                resize_catmullrom_launch<true>(m->d_img_src[b], widths[i], heights[i], (uint32_t)m->image, (uint32_t)m->image,
+                                               m->d_img_tmp, nullptr, m->d_in + j * px, m->stream);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipEventRecord(m->ev_used[b], m->stream));
+            }
+            forward(m, m->d_in, c, m->d_out, m->stream);
+            HIP_CHECK(hipMemcpyAsync(out + i0 * m->E, m->d_out, c * m->E * 4, hipMemcpyDeviceToHost, m->stream));
             HIP_CHECK(hipStreamSynchronize(m->stream));
         }
     });

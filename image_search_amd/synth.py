@@ -65,6 +65,21 @@ def images_u8(seed: int, n: int, size: int = 224) -> np.ndarray:
         return (_mix64(i + key) >> np.uint64(56)).astype(np.uint8).reshape(n, size, size, 3)
 
 
+def photo_u8(seed: int, height: int, width: int) -> np.ndarray:
+    """A seeded photo-like RGB8 image [height,width,3]: smooth structure at several scales plus
+    per-pixel noise from the counter generator, so that a resampler sees both gradients and
+    high-frequency content (stand-in for a decoded JPEG, server/src/clip.rs:92-104)."""
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    base = np.stack([128 + 70 * np.sin(xx / 17.0 + seed) + 40 * np.cos(yy / 23.0),
+                     255.0 * xx / max(width - 1, 1),
+                     255.0 * yy / max(height - 1, 1) * (0.5 + 0.5 * np.sin(xx / 5.0))], -1)
+    with np.errstate(over="ignore"):
+        key = _mix64(np.array([seed ^ 0x5EED], dtype=np.uint64) + _GOLDEN)[0]
+        i = np.arange(height * width * 3, dtype=np.uint64)
+        noise = ((_mix64(i + key) >> np.uint64(58)).astype(np.float64) - 32.0).reshape(height, width, 3)
+    return np.clip(base + noise, 0, 255).astype(np.uint8)
+
+
 def preprocess_rgb8(hwc: np.ndarray) -> np.ndarray:
     """image_prepare_resnet's arithmetic, server/src/clip.rs:158-172: p/255, minus
     ImageNet mean, divided by ImageNet std, planar CHW f32 (fp32 ops throughout)."""

@@ -94,6 +94,27 @@ int mi_clip_embed_rgb8(mi_clip* m, const uint8_t* rgb8, size_t n, float* out);
  * reference's two-step flow: rgb8 [n,H,W,3] -> chw f32 [n,3,H,W]. */
 int mi_preprocess_rgb8(const uint8_t* rgb8, size_t n, uint32_t height, uint32_t width, float* chw);
 
+/* The resize in front of that arithmetic: `img.resize_exact(224, 224, FilterType::CatmullRom)`
+ * (server/src/clip.rs:154), i.e. image-0.25.8's separable resampler (Cargo.lock:5008-5009;
+ * imageops/sample.rs: vertical pass into f32, horizontal pass, clamp, round half away from zero),
+ * run on GPU `device`.  rgb8 = [height][width][3] interleaved u8 (a decoded photo; RGBA / grey
+ * inputs give the same RGB bytes when expanded first, the crate filters channels independently),
+ * out = [new_height][new_width][3].  Equal sizes copy, as the crate does.  Extents up to 32768 and
+ * reductions up to 255x; zero extents and sizes beyond those limits return MI_ERR_UNSUPPORTED. */
+int mi_resize_catmullrom_rgb8(int device, const uint8_t* rgb8, uint32_t width, uint32_t height, uint32_t new_width,
+                              uint32_t new_height, uint8_t* out);
+
+/* image_prepare_resnet whole (server/src/clip.rs:153-175): one decoded RGB8 image of any size ->
+ * chw f32 [3][224][224], resize and normalisation fused on the device. */
+int mi_image_prepare_resnet(int device, const uint8_t* rgb8, uint32_t width, uint32_t height, float* chw);
+
+/* One chunk of the scan loop (server/src/clip.rs:92-124) in one call: n decoded RGB8 images of
+ * any sizes (rgb8[i] = [heights[i]][widths[i]][3], host pointers) -> resize + normalise on the
+ * device straight into the tower's input -> out [n,768] f32.  Uploads overlap the resize of the
+ * previous image. */
+int mi_clip_embed_images(mi_clip* m, const uint8_t* const* rgb8, const uint32_t* widths, const uint32_t* heights,
+                         size_t n, float* out);
+
 /* ---------------------------------------------------------------- Seam B: kNN */
 
 /* One shard of table `image{embedding}` (server/src/search.rs:13-18; index DDL

@@ -119,3 +119,26 @@ def orc_merge(lib, idx_lists, dist_lists, k):
     lib.orc_merge(idx_in.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), _fp(dist_in), lists, k,
                   idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), _fp(dist))
     return idx, dist
+
+
+def orc_resize_catmullrom(lib, rgb8_hwc, nwidth, nheight):
+    """image-0.25.8 resize_exact(.., CatmullRom) restated (oracle.c orc_resize_catmullrom_rgb8)."""
+    a = np.ascontiguousarray(rgb8_hwc, np.uint8)
+    out = np.zeros((nheight, nwidth, 3), np.uint8)
+    lib.orc_resize_catmullrom_rgb8.restype = ctypes.c_int
+    rc = lib.orc_resize_catmullrom_rgb8(ctypes.c_void_p(a.ctypes.data), ctypes.c_uint32(a.shape[1]), ctypes.c_uint32(a.shape[0]),
+                                        ctypes.c_uint32(nwidth), ctypes.c_uint32(nheight), ctypes.c_void_p(out.ctypes.data))
+    if rc != 0:
+        raise RuntimeError("orc_resize_catmullrom_rgb8 failed")
+    return out
+
+
+def orc_image_prepare_resnet(lib, rgb8_hwc):
+    a = np.ascontiguousarray(rgb8_hwc, np.uint8)
+    out = np.zeros((3, 224, 224), np.float32)
+    lib.orc_image_prepare_resnet.restype = ctypes.c_int
+    rc = lib.orc_image_prepare_resnet(ctypes.c_void_p(a.ctypes.data), ctypes.c_uint32(a.shape[1]), ctypes.c_uint32(a.shape[0]),
+                                      ctypes.c_void_p(out.ctypes.data))
+    if rc != 0:
+        raise RuntimeError("orc_image_prepare_resnet failed")
+    return out

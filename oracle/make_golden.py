@@ -99,12 +99,36 @@ def misc_golden():
     np.savez(os.path.join(GOLD, "gen.npz"), s7=synth.gen_f32(7, 0, 64), s7_off=synth.gen_f32(7, 1 << 40, 64, 0.02))
 
 
+def resize_golden():
+    """image_prepare_resnet's resize (server/src/clip.rs:154; image-0.25.8 CatmullRom).  Nothing in
+    the reference pins a resized pixel, so two things are stored per case: the oracle's own output
+    (regression pin) and an INDEPENDENT implementation of the same filter -- torch's antialiased
+    bicubic (A = -0.5 Catmull-Rom, support scaled by the ratio, normalised weights; the
+    Pillow-compatible resampler) -- which must agree within one grey level."""
+    import torch
+    import torch.nn.functional as F
+    from oracle.binding import load_oracle, orc_resize_catmullrom
+    lib = load_oracle()
+    out = {}
+    for name, seed, h, w in (("down", 3, 300, 401), ("up", 4, 37, 53), ("mixed", 5, 1000, 61)):
+        img = synth.photo_u8(seed, h, w)
+        t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
+        ind = F.interpolate(t, size=(224, 224), mode="bicubic", antialias=True, align_corners=False)
+        out[f"{name}_seed"], out[f"{name}_hw"] = seed, np.array([h, w])
+        out[f"{name}_oracle"] = orc_resize_catmullrom(lib, img, 224, 224)
+        aa = ind[0].permute(1, 2, 0).clamp(0, 255).round().numpy().astype(np.uint8)
+        diff = np.flatnonzero(aa.ravel() != out[f"{name}_oracle"].ravel())  # stored sparsely: a few pixels, +-1
+        out[f"{name}_torch_aa_diff_idx"], out[f"{name}_torch_aa_diff_val"] = diff, aa.ravel()[diff]
+    np.savez_compressed(os.path.join(GOLD, "resize.npz"), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     misc_golden()
+    resize_golden()
     knn_golden()
     vit_golden(synth.VitConfig.tiny(), "tiny", 3, 1)
     if a.full:

@@ -104,6 +104,91 @@ void orc_preprocess_rgb8(const uint8_t* hwc, size_t n_images, float* chw) {
             }
 }
 
+/* ---- image_prepare_resnet, resize part: server/src/clip.rs:154-155 ----
+ * `img.resize_exact(224, 224, FilterType::CatmullRom)` then `.to_rgb8()`.  The resampler lives in the
+ * un-vendored `image` crate, pinned at 0.25.8 (Cargo.lock:5008-5009); its source is absent from
+ * /root/reference, so this restates the published algorithm of image-0.25.8 src/imageops/sample.rs
+ * (`resize` -> `vertical_sample` into an f32 image -> `horizontal_sample` with clamp + round-to-nearest,
+ * kernel `catmullrom_kernel(x) = bc_cubic_spline(x, 0.0, 0.5)`, support 2.0) -- PARITY UNPINNED: no test
+ * or fixture of the reference pins a resized pixel.  Every operation is fp32 in the order
+ * the crate writes it: weights w_i = k((i - (centre - 0.5)) / sratio) for i in [left, right), their sum
+ * accumulated in that order, each weight divided by the sum, then t += p_i * w_i in that order.
+ * RGB8 input only (what a decoded JPEG is); resizing RGBA8 / L8 and converting afterwards gives the same
+ * RGB bytes because the crate filters every channel independently. */
+static inline float orc_catmullrom(float x) {
+    const float a = fabsf(x);
+    float k;
+    if (a < 1.0f) k = (9.0f * ((a * a) * a) + -15.0f * (a * a)) + 6.0f;
+    else if (a < 2.0f) k = ((-3.0f * ((a * a) * a) + 15.0f * (a * a)) + -24.0f * a) + 12.0f;
+    else k = 0.0f;
+    return k / 6.0f;
+}
+
+/* window [left, right) and the centre used by the kernel, for output index `o` of `n_out` over `n_in` */
+static inline void orc_window(uint32_t o, uint32_t n_in, uint32_t n_out, int64_t* left, int64_t* right,
+                              float* centre, float* sratio) {
+    const float ratio = (float)n_in / (float)n_out;
+    *sratio = ratio < 1.0f ? 1.0f : ratio;
+    const float support = 2.0f * *sratio;
+    const float in = ((float)o + 0.5f) * ratio;
+    int64_t l = (int64_t)floorf(in - support);
+    if (l < 0) l = 0;
+    if (l > (int64_t)n_in - 1) l = (int64_t)n_in - 1;
+    int64_t r = (int64_t)ceilf(in + support);
+    if (r < l + 1) r = l + 1;
+    if (r > (int64_t)n_in) r = (int64_t)n_in;
+    *left = l; *right = r; *centre = in - 0.5f;
+}
+
+/* src [h][w][3] u8 -> dst [nh][nw][3] u8; returns 0, or -1 on bad sizes / allocation failure */
+int orc_resize_catmullrom_rgb8(const uint8_t* src, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint8_t* dst) {
+    if (nw == 0 || nh == 0) return -1;
+    if (w == 0 || h == 0) { memset(dst, 0, (size_t)nw * nh * 3); return 0; }  /* ImageBuffer::new: zeros */
+    if (w == nw && h == nh) { memcpy(dst, src, (size_t)w * h * 3); return 0; }
+    float* tmp = (float*)malloc((size_t)nh * w * 3 * sizeof(float));
+    if (!tmp) return -1;
+    float* ws = (float*)malloc(((size_t)(h > w ? h : w) + 1) * sizeof(float));
+    if (!ws) { free(tmp); return -1; }
+    for (uint32_t oy = 0; oy < nh; ++oy) {  /* vertical_sample */
+        int64_t l, r; float c, sr;
+        orc_window(oy, h, nh, &l, &r, &c, &sr);
+        float sum = 0.0f;
+        for (int64_t i = l; i < r; ++i) { ws[i - l] = orc_catmullrom(((float)i - c) / sr); sum += ws[i - l]; }
+        for (int64_t i = l; i < r; ++i) ws[i - l] /= sum;
+        for (size_t e = 0; e < (size_t)w * 3; ++e) {
+            float t = 0.0f;
+            for (int64_t i = l; i < r; ++i) t += (float)src[(size_t)i * w * 3 + e] * ws[i - l];
+            tmp[(size_t)oy * w * 3 + e] = t;
+        }
+    }
+    for (uint32_t ox = 0; ox < nw; ++ox) {  /* horizontal_sample */
+        int64_t l, r; float c, sr;
+        orc_window(ox, w, nw, &l, &r, &c, &sr);
+        float sum = 0.0f;
+        for (int64_t i = l; i < r; ++i) { ws[i - l] = orc_catmullrom(((float)i - c) / sr); sum += ws[i - l]; }
+        for (int64_t i = l; i < r; ++i) ws[i - l] /= sum;
+        for (uint32_t y = 0; y < nh; ++y)
+            for (int ch = 0; ch < 3; ++ch) {
+                float t = 0.0f;
+                for (int64_t i = l; i < r; ++i) t += tmp[((size_t)y * w + (size_t)i) * 3 + ch] * ws[i - l];
+                t = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);  /* clamp(t, min, max); NaN cannot occur */
+                dst[((size_t)y * nw + ox) * 3 + ch] = (uint8_t)roundf(t);  /* FloatNearest: half away from zero */
+            }
+    }
+    free(ws); free(tmp);
+    return 0;
+}
+
+/* the whole of image_prepare_resnet (server/src/clip.rs:153-175): one RGB8 image of any size -> CHW f32 */
+int orc_image_prepare_resnet(const uint8_t* src, uint32_t w, uint32_t h, float* chw) {
+    uint8_t* r = (uint8_t*)malloc((size_t)224 * 224 * 3);
+    if (!r) return -1;
+    const int rc = orc_resize_catmullrom_rgb8(src, w, h, 224, 224, r);
+    if (rc == 0) orc_preprocess_rgb8(r, 1, chw);
+    free(r);
+    return rc;
+}
+
 /* ---- cosine distance in the fixed summation order ---- */
 
 static inline void orc_dot2(const float* q, const float* x, uint32_t dim, float* dot, float* xx) {
