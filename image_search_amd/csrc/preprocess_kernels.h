@@ -59,19 +59,34 @@ __device__ __forceinline__ int resize_weights(float* ws, const ResizeWindow& wd)
     return nt;
 }
 
-// grid (ceil(3w / 256), nh), 256 threads
-static __global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t* __restrict__ src, uint32_t w, uint32_t h,
+// grid (ceil(3w / (256 * V)), nh), 256 threads; a thread owns V consecutive bytes of the row
+// (V = 4 when the row pitch 3w is a multiple of 4: one dword load per tap instead of four byte loads)
+template <int V>
+__global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t* __restrict__ src, uint32_t w, uint32_t h,
                                                        uint32_t nh, float* __restrict__ tmp) {
     __shared__ float ws[RESIZE_MAX_TAPS];
     const uint32_t oy = blockIdx.y;
     const ResizeWindow wd = resize_window(oy, h, nh);
     const int nt = resize_weights(ws, wd);
-    const size_t row = (size_t)w * 3, e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = (size_t)w * 3, e = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
     if (e >= row) return;
     const uint8_t* p = src + (size_t)wd.left * row + e;
-    float t = 0.0f;
-    for (int i = 0; i < nt; ++i) t += (float)p[(size_t)i * row] * ws[i];
-    tmp[(size_t)oy * row + e] = t;
+    float t[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) t[v] = 0.0f;
+    for (int i = 0; i < nt; ++i) {
+        const float wi = ws[i];
+        if constexpr (V == 4) {
+            const uint32_t q = *reinterpret_cast<const uint32_t*>(p + (size_t)i * row);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) t[v] += (float)((q >> (8 * v)) & 0xffu) * wi;
+        } else {
+            t[0] += (float)p[(size_t)i * row] * wi;
+        }
+    }
+    float* o = tmp + (size_t)oy * row + e;
+    if constexpr (V == 4) *reinterpret_cast<float4*>(o) = make_float4(t[0], t[1], t[2], t[3]);
+    else o[0] = t[0];
 }
 
 // grid (nw), 256 threads; thread y handles output rows y, y + 256, ...
@@ -124,13 +139,17 @@ __global__ void resize_copy_kernel(const uint8_t* __restrict__ src, size_t n_px,
 
 // d_src [h][w][3] u8 (device) -> d_u8 [nh][nw][3] or d_chw [3][nh][nw]; d_tmp holds nh*w*3 floats
 template <bool TO_CHW>
-static inline void resize_catmullrom_launch(const uint8_t* d_src, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh,
+inline void resize_catmullrom_launch(const uint8_t* d_src, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh,
                                      float* d_tmp, uint8_t* d_u8, float* d_chw, hipStream_t s) {
     if (w == nw && h == nh) {
         hipLaunchKernelGGL((resize_copy_kernel<TO_CHW>), dim3(256), dim3(256), 0, s, d_src, (size_t)w * h, d_u8, d_chw);
         return;
     }
-    hipLaunchKernelGGL(resize_v_kernel, dim3((unsigned)(((size_t)w * 3 + 255) / 256), nh), dim3(256), 0, s, d_src, w, h, nh, d_tmp);
+    const size_t row = (size_t)w * 3;
+    if (row % 4 == 0 && reinterpret_cast<uintptr_t>(d_src) % 4 == 0)
+        hipLaunchKernelGGL((resize_v_kernel<4>), dim3((unsigned)((row / 4 + 255) / 256), nh), dim3(256), 0, s, d_src, w, h, nh, d_tmp);
+    else
+        hipLaunchKernelGGL((resize_v_kernel<1>), dim3((unsigned)((row + 255) / 256), nh), dim3(256), 0, s, d_src, w, h, nh, d_tmp);
     hipLaunchKernelGGL((resize_h_kernel<TO_CHW>), dim3(nw), dim3(256), 0, s, d_tmp, w, nw, nh, d_u8, d_chw);
 }
 
