@@ -42,6 +42,8 @@ SYMBOLS = {
     "mi_knn_append_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint64, c_vp]),
     "mi_knn_append_synthetic": (ctypes.c_int, [c_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]),
     "mi_knn_get_rows": (ctypes.c_int, [c_vp, ctypes.c_uint64, ctypes.c_uint64, c_vp]),
+    "mi_knn_save": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
+    "mi_knn_load": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
     "mi_knn_search": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     "mi_knn_search_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp]),
     "mi_knn_search_batched_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp]),

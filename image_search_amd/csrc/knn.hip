@@ -3,6 +3,7 @@
 // (server/src/search.rs:13-18) resident in HBM on one GPU.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -330,6 +331,80 @@ int mi_knn_get_rows(mi_knn* t, uint64_t first, uint64_t n, float* out) {
         HIP_CHECK(hipMemcpyAsync(out, t->table + first * t->dim, n * t->dim * sizeof(float), hipMemcpyDeviceToHost,
                                  t->stream));
         HIP_CHECK(hipStreamSynchronize(t->stream));
+    });
+}
+
+// ---- persistence of a shard: what SurrealDB's storage does for
+// `image.embedding` (server/src/clip.rs:125-137).  File = 32-byte header {"MIKNNv01", u32 dim,
+// u32 reserved, u64 rows, u64 base} + rows*dim little-endian f32, streamed through a 64 MiB
+// pinned buffer so that neither side needs the table in host memory.
+namespace {
+struct KnnFileHeader { char magic[8]; uint32_t dim, reserved; uint64_t rows, base; };
+static_assert(sizeof(KnnFileHeader) == 32, "header layout");
+constexpr size_t IO_CHUNK = 64u << 20;
+struct PinnedBuf {
+    void* p = nullptr;
+    explicit PinnedBuf(size_t b) { HIP_CHECK(hipHostMalloc(&p, b, hipHostMallocDefault)); }
+    ~PinnedBuf() { (void)hipHostFree(p); }
+};
+struct File {
+    FILE* f;
+    File(const char* path, const char* mode) : f(std::fopen(path, mode)) {}
+    ~File() { if (f) std::fclose(f); }
+};
+}  // namespace
+
+int mi_knn_save(mi_knn* t, const char* path) {
+    return guarded([&] {
+        if (!t) fail(MI_ERR_INVALID, "null table handle");
+        if (!path) fail(MI_ERR_INVALID, "path is null");
+        std::lock_guard<std::mutex> l(t->mu);
+        DeviceGuard g(t->device);
+        own_stream(t);
+        File f(path, "wb");
+        if (!f.f) fail(MI_ERR_IO, "cannot create %s", path);
+        KnnFileHeader h{};
+        std::memcpy(h.magic, "MIKNNv01", 8);
+        h.dim = t->dim; h.rows = t->rows; h.base = t->base;
+        if (std::fwrite(&h, sizeof h, 1, f.f) != 1) fail(MI_ERR_IO, "write to %s failed", path);
+        const size_t total = (size_t)t->rows * t->dim * sizeof(float);
+        if (total == 0) return;
+        PinnedBuf buf(std::min(total, IO_CHUNK));
+        for (size_t off = 0; off < total; off += IO_CHUNK) {
+            const size_t n = std::min(IO_CHUNK, total - off);
+            HIP_CHECK(hipMemcpyAsync(buf.p, (const char*)t->table + off, n, hipMemcpyDeviceToHost, t->stream));
+            HIP_CHECK(hipStreamSynchronize(t->stream));
+            if (std::fwrite(buf.p, 1, n, f.f) != n) fail(MI_ERR_IO, "write to %s failed", path);
+        }
+    });
+}
+
+int mi_knn_load(mi_knn* t, const char* path) {
+    return guarded([&] {
+        if (!t) fail(MI_ERR_INVALID, "null table handle");
+        if (!path) fail(MI_ERR_INVALID, "path is null");
+        std::lock_guard<std::mutex> l(t->mu);
+        DeviceGuard g(t->device);
+        own_stream(t);
+        File f(path, "rb");
+        if (!f.f) fail(MI_ERR_IO, "cannot open %s", path);
+        KnnFileHeader h{};
+        if (std::fread(&h, sizeof h, 1, f.f) != 1 || std::memcmp(h.magic, "MIKNNv01", 8) != 0)
+            fail(MI_ERR_IO, "%s is not a MIKNNv01 shard file", path);
+        if (h.dim != t->dim) fail(MI_ERR_INVALID, "%s holds dim %u rows, the table has dim %u", path, h.dim, t->dim);
+        if (t->rows == 0) t->base = h.base;  // an empty table takes the shard's id range
+        const size_t total = (size_t)h.rows * t->dim * sizeof(float);
+        if (total == 0) return;
+        grow(t, t->rows + h.rows);
+        PinnedBuf buf(std::min(total, IO_CHUNK));
+        char* dst = (char*)(t->table + t->rows * t->dim);
+        for (size_t off = 0; off < total; off += IO_CHUNK) {
+            const size_t n = std::min(IO_CHUNK, total - off);
+            if (std::fread(buf.p, 1, n, f.f) != n) fail(MI_ERR_IO, "%s is truncated", path);
+            HIP_CHECK(hipMemcpyAsync(dst + off, buf.p, n, hipMemcpyHostToDevice, t->stream));
+            HIP_CHECK(hipStreamSynchronize(t->stream));
+        }
+        t->rows += h.rows;
     });
 }
 

@@ -160,3 +160,133 @@ def gather_and_merge(local_idx: np.ndarray, local_dist: np.ndarray, k: int, grou
     for u in range(nq):
         out_i[u], out_d[u] = merge_candidates(gi[:, u, :], gd[:, u, :], k)
     return out_i, out_d
+
+
+class ImageIndex:
+    """Table `image` {id, image_path, embedding} (search.rs:13-18; rows inserted at clip.rs:125-137)
+    as one HBM shard plus a host-side `image_path` column.  Row id = insertion ordinal.
+    Covers the statements the server issues against that table:
+      `SELECT image_path FROM image WHERE image_path IN $paths`              -> existing()
+      `db.insert("image").content(rows)`                                     -> insert()
+      `SELECT id, image_path, embedding FROM image WHERE image_path IN $p`   -> embeddings_of()
+      `SELECT id, image_path, knn() FROM image WHERE embedding <|K|> $ref`   -> web_search_text()
+    and keeps them across restarts (save / load), which the database did for the reference."""
+
+    def __init__(self, dim: int = 768, device: int = 0, media_dir: str = ""):
+        self.table = EmbeddingTable(dim, device)
+        self.paths: list[str] = []
+        self._row_of: dict[str, list[int]] = {}
+        self.media_dir = media_dir
+
+    def __len__(self) -> int:
+        return len(self.paths)
+
+    def existing(self, paths: Sequence[str]) -> set:
+        """clip.rs:74-83: which of `paths` already have a row."""
+        return {p for p in paths if p in self._row_of}
+
+    def insert(self, paths: Sequence[str], embeddings: np.ndarray):
+        """clip.rs:125-137: one row per (image_path, embedding) pair, ids in insertion order.  Like
+        the reference's table there is no uniqueness constraint; the scan loop filters first."""
+        e = _f32(embeddings).reshape(-1, self.table.dim)
+        if e.shape[0] != len(paths):
+            raise ValueError(f"{len(paths)} paths for {e.shape[0]} embeddings")
+        self.table.insert(e)
+        for p in paths:
+            self._row_of.setdefault(p, []).append(len(self.paths))
+            self.paths.append(p)
+
+    def embeddings_of(self, paths: Sequence[str]):
+        """search.rs:43-58.  Rows come back in table (id) order, whatever the request order — the
+        order matters: average_slices adds in input order (search.rs:139-143)."""
+        rows = sorted({r for p in set(paths) for r in self._row_of.get(p, ())})
+        return rows, [self.table.rows(r, 1)[0] for r in rows]
+
+    def _to_disk(self, web_path: str) -> str:
+        return web_path.replace("media/", self.media_dir, 1)
+
+    def web_search_text(self, text_embedding: np.ndarray, referenced_images: Sequence[str] = (), k: int = K_REFERENCE):
+        """search.rs:20-110 after the text tower: refine with the marked images that are in the
+        table, K nearest by cosine distance, paths mapped back under `media/`.
+        Returns [(id, image_path, similarity)] with similarity = vector::distance::knn()."""
+        query = _f32(text_embedding).reshape(-1)
+        marked = [self._to_disk(p) for p in referenced_images if p.startswith("media/")]   # search.rs:35-40
+        if marked:
+            _, selected = self.embeddings_of(marked)
+            if selected:                                                                  # search.rs:59-67
+                query = refine_query(query, selected)
+        idx, dist = self.table.knn(query, k)
+        out = []
+        for i, d in zip(idx, dist):
+            if i == NO_ID:
+                break
+            p = self.paths[int(i)]
+            out.append((int(i), p.replace(self.media_dir, "media/") if self.media_dir else p, float(d)))
+        return out
+
+    def save(self, directory: str):
+        import json
+        import os
+        os.makedirs(directory, exist_ok=True)
+        check(lib().mi_knn_save(self.table._h, os.path.join(directory, "embedding.miknn").encode()))
+        with open(os.path.join(directory, "image_path.json"), "w") as f:
+            json.dump({"media_dir": self.media_dir, "image_path": self.paths}, f)
+
+    @classmethod
+    def load(cls, directory: str, device: int = 0, dim: int = 768) -> "ImageIndex":
+        import json
+        import os
+        with open(os.path.join(directory, "image_path.json")) as f:
+            meta = json.load(f)
+        ix = cls(dim, device, meta["media_dir"])
+        check(lib().mi_knn_load(ix.table._h, os.path.join(directory, "embedding.miknn").encode()))
+        if len(ix.table) != len(meta["image_path"]):
+            raise ValueError(f"{directory}: {len(ix.table)} embeddings for {len(meta['image_path'])} paths")
+        for p in meta["image_path"]:
+            ix._row_of.setdefault(p, []).append(len(ix.paths))
+            ix.paths.append(p)
+        return ix
+
+
+def embed_all_images_in_dir(model, index: ImageIndex, media_dir: str, image_chunk_size: int = 500, decode=None,
+                            shuffle_seed=None) -> int:
+    """clip.rs:42-151: walk `media_dir` (following links), keep the allow-listed extensions, shuffle,
+    and per chunk: skip paths that already have a row, decode, embed (resize + normalise + tower on
+    the device: Model.forward_images), insert.  A crash loses at most one chunk; a rerun resumes.
+    `decode(path) -> RGB8 [H,W,3]` defaults to Pillow; files that fail to decode are logged and
+    skipped TOGETHER WITH their path (the reference zips the unfiltered path list with the
+    surviving embeddings, clip.rs:125-134, which shifts paths after a failure).  Returns rows added."""
+    import logging
+    import os
+    import random
+    from .clip import is_image_path
+    if decode is None:
+        from PIL import Image
+
+        def decode(path):
+            with Image.open(path) as im:
+                return np.asarray(im.convert("RGB"), np.uint8)
+    paths = []
+    for root, _, files in os.walk(media_dir, followlinks=True):
+        for name in files:
+            p = os.path.join(root, name)
+            if os.path.isfile(p) and is_image_path(p):
+                paths.append(p)
+    random.Random(shuffle_seed).shuffle(paths)
+    added = 0
+    for c0 in range(0, len(paths), image_chunk_size):
+        chunk = paths[c0:c0 + image_chunk_size]
+        have = index.existing(chunk)
+        new_paths, images = [], []
+        for p in chunk:
+            if p in have:
+                continue
+            try:
+                images.append(decode(p))
+                new_paths.append(p)
+            except Exception as err:  # noqa: BLE001 — mirrors `Failed to open image` (clip.rs:98-101)
+                logging.getLogger(__name__).error("Failed to open image %s: %s", p, err)
+        if new_paths:
+            index.insert(new_paths, model.forward_images(images))
+            added += len(new_paths)
+    return added

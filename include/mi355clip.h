@@ -140,6 +140,13 @@ int mi_knn_append_synthetic(mi_knn* t, uint64_t seed, uint64_t first_row, uint64
  * server/src/search.rs:43-58) */
 int mi_knn_get_rows(mi_knn* t, uint64_t first, uint64_t n, float* out);
 
+/* Persistence of a shard (what the database's storage does for `image.embedding`,
+ * server/src/clip.rs:125-137): mi_knn_save writes {32-byte header, rows*dim f32} to `path`;
+ * mi_knn_load appends a file's rows to the table (an empty table also takes the file's id base).
+ * Streamed in 64 MiB pieces: no host copy of the table on either side. */
+int mi_knn_save(mi_knn* t, const char* path);
+int mi_knn_load(mi_knn* t, const char* path);
+
 /* Replaces `SELECT id, image_path, vector::distance::knn() FROM image WHERE
  * embedding <|K|> $reference` (server/src/search.rs:70-86; K = 1000 there).
  * For each of nq queries (q: [nq,dim] host f32): the k rows of this shard with the
