@@ -56,6 +56,13 @@ inline std::vector<float> image_prepare_resnet(const std::vector<uint8_t>& rgb8,
     return out;
 }
 
+// image_prepare_resnet whole (clip.rs:153-175): one decoded RGB8 image of any size -> CHW f32 [3][224][224]
+inline std::vector<float> image_prepare_resnet(const uint8_t* rgb8, uint32_t width, uint32_t height, int device = 0) {
+    std::vector<float> out((size_t)3 * 224 * 224);
+    check(mi_image_prepare_resnet(device, rgb8, width, height, out.data()));
+    return out;
+}
+
 namespace clip_vit_large_patch14 {
 class Model {
     mi_clip* h_ = nullptr;
@@ -81,6 +88,17 @@ class Model {
         check(mi_clip_embed(h_, nchw.data(), n, out.data()));
         return out;
     }
+    // one chunk of the scan loop (clip.rs:92-124): decoded RGB8 images of any sizes -> [n,proj] f32;
+    // CatmullRom resize_exact + normalisation + tower on the device
+    struct Rgb8 { const uint8_t* data; uint32_t width, height; };
+    std::vector<float> forward_images(const std::vector<Rgb8>& images) const {
+        std::vector<const uint8_t*> p;
+        std::vector<uint32_t> w, h;
+        for (const auto& im : images) { p.push_back(im.data); w.push_back(im.width); h.push_back(im.height); }
+        std::vector<float> out(images.size() * proj());
+        check(mi_clip_embed_images(h_, p.data(), w.data(), h.data(), images.size(), out.data()));
+        return out;
+    }
 };
 }  // namespace clip_vit_large_patch14
 
@@ -98,6 +116,9 @@ class EmbeddingTable {
     ~EmbeddingTable() { mi_knn_free(h_); }
     void insert(const std::vector<float>& rows) { check(mi_knn_append(h_, rows.data(), rows.size() / dim_)); }
     uint64_t size() const { uint64_t n = 0; check(mi_knn_size(h_, &n)); return n; }
+    // what the database's storage did for the reference: one file per shard
+    void save(const std::string& path) const { check(mi_knn_save(h_, path.c_str())); }
+    void load(const std::string& path) { check(mi_knn_load(h_, path.c_str())); }
     // `WHERE embedding <|k|> $reference`: ids and cosine distances, ascending
     std::pair<std::vector<uint64_t>, std::vector<float>> knn(const std::vector<float>& reference, uint32_t k = 1000) const {
         std::vector<uint64_t> idx(k);
