@@ -27,6 +27,8 @@ SYMBOLS = {
     "mi_clip_embed": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "mi_clip_embed_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "mi_clip_embed_rgb8": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "mi_clip_load_text": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "mi_clip_embed_text": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "mi_preprocess_rgb8": (ctypes.c_int, [c_vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, c_vp]),
     "mi_resize_catmullrom_rgb8": (ctypes.c_int, [ctypes.c_int, c_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                                  ctypes.c_uint32, c_vp]),

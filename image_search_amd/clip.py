@@ -116,5 +116,38 @@ class Model:
         check(lib().mi_clip_embed_device(self._h, d_nchw, n, d_out, stream))
 
 
+class TextModel:
+    """The CLIP text tower on one MI355X: what `clip(state, text)` obtains from embed_anything
+    (server/src/clip.rs:19-23, :35-40).  `embed(input_ids)` takes tokenizer output
+    [n, positions] (BOS .. EOS, padded) and returns [n, proj] f32."""
+
+    def __init__(self, handle: c_vp):
+        self._h = handle
+        info = (ctypes.c_uint32 * 8)()
+        check(lib().mi_clip_info(self._h, info))
+        (_, _, self.positions, self.hidden, self.layers, self.heads, self.ff, self.proj) = list(info)
+
+    @classmethod
+    def from_file(cls, path: str, device: int = 0) -> "TextModel":
+        h = c_vp()
+        check(lib().mi_clip_load_text(path.encode(), device, PRECISION_F32, ctypes.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mi_clip_free(self._h)
+            self._h = c_vp()
+
+    __del__ = close
+
+    def embed(self, input_ids: np.ndarray) -> np.ndarray:
+        ids = np.ascontiguousarray(input_ids, np.int32)
+        if ids.ndim != 2 or ids.shape[1] != self.positions:
+            raise ValueError(f"expected [n,{self.positions}] token ids, got {ids.shape}")
+        out = np.empty((ids.shape[0], self.proj), np.float32)
+        check(lib().mi_clip_embed_text(self._h, ids.ctypes.data, ids.shape[0], out.ctypes.data))
+        return out
+
+
 class clip_vit_large_patch14:  # noqa: N801 — the reference's module name
     Model = Model

@@ -206,6 +206,12 @@ struct mi_clip {
     int parts = 2;  // MI_CLIP_PARTS: sub-chunks run as independent streams
     int n_cu = 256;
     uint8_t* d_rgb = nullptr;
+    // text tower (mi_clip_load_text): token table, device copies of the ids and of the EOS rows
+    bool text = false;
+    int vocab = 0;
+    float* tok = nullptr;
+    int *d_ids = nullptr, *d_rows = nullptr;
+    size_t text_cap = 0;
     // mi_clip_embed_images: two upload buffers for decoded images, the resize intermediate, a copy stream
     uint8_t* d_img_src[2] = {nullptr, nullptr};
     float* d_img_tmp = nullptr;
@@ -246,6 +252,44 @@ void* upload_mat(mi_clip* m, const std::vector<float>& h) {
     uint16_t* d = dalloc<uint16_t>(m, b.size(), m->allocs);
     HIP_CHECK(hipMemcpy(d, b.data(), b.size() * 2, hipMemcpyHostToDevice));
     return d;
+}
+
+void load_layers(mi_clip* m, SafeTensors& st, const std::string& prefix);
+
+// The text tower of the same checkpoint family (HF `CLIPTextModelWithProjection` names): what the
+// reference reaches through embed_anything (server/src/clip.rs:19-23, :35-40).  fp32 only: one
+// query is 77 token rows, latency-bound, and the causal mask exists in the fp32 attention kernel.
+void load_text_weights(mi_clip* m, const char* path) {
+    SafeTensors st(path);
+    const std::string t = "text_model.";
+    const TensorInfo& te = st.info(t + "embeddings.token_embedding.weight");
+    if (te.shape.size() != 2) fail(MI_ERR_UNSUPPORTED, "token_embedding.weight must be [V,D]");
+    m->vocab = (int)te.shape[0];
+    m->D = (int)te.shape[1];
+    const TensorInfo& po = st.info(t + "embeddings.position_embedding.weight");
+    if (po.shape.size() != 2 || po.shape[1] != m->D) fail(MI_ERR_UNSUPPORTED, "position_embedding.weight must be [S,D]");
+    m->S = (int)po.shape[0];
+    int L = 0;
+    while (st.has(t + "encoder.layers." + std::to_string(L) + ".layer_norm1.weight")) ++L;
+    if (L == 0) fail(MI_ERR_IO, "no text encoder layers found in '%s'", path);
+    m->L = L;
+    m->FF = (int)st.info(t + "encoder.layers.0.mlp.fc1.weight").shape.at(0);
+    m->E = (int)st.info("text_projection.weight").shape.at(0);
+    m->H = m->D / 64;
+    auto it = st.meta.find("num_attention_heads");
+    if (it != st.meta.end()) m->H = std::atoi(it->second.c_str());
+    if (m->H <= 0 || m->D != m->H * 64)
+        fail(MI_ERR_UNSUPPORTED, "hidden %d with %d heads: the attention kernels are built for head_dim 64", m->D, m->H);
+    if (m->D % 128 != 0 || m->FF % 128 != 0)
+        fail(MI_ERR_UNSUPPORTED, "hidden (%d) and intermediate (%d) sizes must be multiples of 128", m->D, m->FF);
+    m->image = m->patch = m->grid = 0;
+    const int D = m->D;
+    m->tok = upload_f32(m, st.read(t + "embeddings.token_embedding.weight", (int64_t)m->vocab * D));
+    m->pos = upload_f32(m, st.read(t + "embeddings.position_embedding.weight", (int64_t)m->S * D));
+    m->post_w = upload_f32(m, st.read(t + "final_layer_norm.weight", D));
+    m->post_b = upload_f32(m, st.read(t + "final_layer_norm.bias", D));
+    m->proj = upload_f32(m, st.read("text_projection.weight", (int64_t)m->E * D));
+    load_layers(m, st, t);
 }
 
 void load_weights(mi_clip* m, const char* path) {
@@ -292,6 +336,12 @@ void load_weights(mi_clip* m, const char* path) {
         for (int d = 0; d < D; ++d) std::memcpy(&wp[(size_t)d * m->Kp], &w[(size_t)d * K], (size_t)K * 4);
         m->wpatch = upload_mat(m, wp);
     }
+    load_layers(m, st, v);
+}
+
+// the encoder blocks: same tensor names under "vision_model." and "text_model."
+void load_layers(mi_clip* m, SafeTensors& st, const std::string& v) {
+    const int D = m->D, FF = m->FF, L = m->L;
     m->layers.resize(L);
     for (int i = 0; i < L; ++i) {
         const std::string p = v + "encoder.layers." + std::to_string(i) + ".";
@@ -458,7 +508,7 @@ void layer_norm(mi_clip* m, float* x, const bf16_t* d1, const bf16_t* d2, bool w
 void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s) {
     if (m->precision == MI_PRECISION_F32) {
         const unsigned blocks = (unsigned)(n * m->H * ((m->S + 63) / 64));
-        hipLaunchKernelGGL(attn_f32_kernel, dim3(blocks), dim3(64), 0, s, (const float*)qkv, (float*)ctx, m->S, m->D, m->H);
+        hipLaunchKernelGGL(attn_f32_kernel, dim3(blocks), dim3(64), 0, s, (const float*)qkv, (float*)ctx, m->S, m->D, m->H, m->text ? 1 : 0);
     } else {
         const unsigned blocks = (unsigned)(n * m->H);
         const int sp = (m->S + 31) / 32 * 32;
@@ -552,13 +602,61 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     for (int p = 0; p < parts; ++p) {
         Part& q = pt[p];
         // fp32 in both precisions: the embedding that goes to the table is not rounded to bf16 anywhere here
-        MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, q.s, q.a->x, q.p1, q.p2, m->post_w, m->post_b, m->proj, q.out, (int)q.n, S, m->E, m->eps));
+        MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, q.s, q.a->x, q.p1, q.p2, m->post_w, m->post_b, m->proj, q.out, (int)q.n, S, m->E, m->eps, (const int*)nullptr));
         HIP_CHECK(hipGetLastError());
     }
     for (int p = 1; p < parts; ++p) {
         HIP_CHECK(hipEventRecord(m->ev_join[p - 1], m->aux[p - 1]));
         HIP_CHECK(hipStreamWaitEvent(s0, m->ev_join[p - 1], 0));
     }
+}
+
+// ---- text tower: workspace and forward (fp32) -------------------------------------------
+void ensure_text_workspace(mi_clip* m, size_t n) {
+    if (n <= m->text_cap) return;
+    own_stream(m);
+    for (void* p : m->ws) HIP_CHECK(hipFree(p));
+    m->ws.clear();
+    m->text_cap = 0;
+    const size_t Ma = pad256(n * m->S);
+    auto bytes = [&](size_t b) {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, b));
+        HIP_CHECK(hipMemsetAsync(p, 0, b, m->stream));
+        m->ws.push_back(p);
+        return p;
+    };
+    m->act[0].x = (float*)bytes(Ma * m->D * 4);
+    m->act[0].y = bytes(Ma * m->D * 4);
+    m->act[0].qkv = bytes(Ma * 3 * m->D * 4);
+    m->act[0].h = bytes(Ma * m->FF * 4);
+    m->d_ids = (int*)bytes(Ma * sizeof(int));
+    m->d_rows = (int*)bytes(n * sizeof(int));
+    m->d_out = (float*)bytes(n * m->E * 4);
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    m->text_cap = n;
+}
+
+// n sequences whose ids are in m->d_ids -> m->d_out [n,E]
+void forward_text(mi_clip* m, size_t n, hipStream_t s) {
+    const int D = m->D, S = m->S, FF = m->FF;
+    const size_t M = n * S;
+    mi_clip::Act& a = m->act[0];
+    hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)std::min<size_t>((M * (D / 4) + 255) / 256, 65535)), dim3(256), 0, s,
+                       m->d_ids, m->tok, m->pos, a.x, M, S, D);
+    hipLaunchKernelGGL(text_eos_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, m->d_ids, (int)n, S, m->d_rows);
+    HIP_CHECK(hipGetLastError());
+    for (const Layer& ly : m->layers) {  // the vision tower's fp32 block with the causal attention
+        layer_norm(m, a.x, nullptr, nullptr, true, a.y, ly.ln1w, ly.ln1b, M, s);
+        gemm<EPI_BIAS>(m, a.y, ly.wqkv, ly.bqkv, a.qkv, M, 3 * D, D, 3 * D, s);
+        attention(m, a.qkv, a.y, n, s);
+        gemm<EPI_BIAS_RESID>(m, a.y, ly.wo, ly.bo, a.x, M, D, D, D, s);
+        layer_norm(m, a.x, nullptr, nullptr, true, a.y, ly.ln2w, ly.ln2b, M, s);
+        gemm<EPI_BIAS_QGELU>(m, a.y, ly.w1, ly.b1, a.h, M, FF, D, FF, s);
+        gemm<EPI_BIAS_RESID>(m, a.h, ly.w2, ly.b2, a.x, M, D, FF, D, s);
+    }
+    MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((n + 7) / 8), 16), dim3(256), 0, s, a.x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, m->post_w, m->post_b, m->proj, m->d_out, (int)n, S, m->E, m->eps, (const int*)m->d_rows));
+    HIP_CHECK(hipGetLastError());
 }
 
 void free_model(mi_clip* m) {
@@ -614,6 +712,52 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
 
 void mi_clip_free(mi_clip* m) { free_model(m); }
 
+int mi_clip_load_text(const char* weights_path, int device, int precision, mi_clip** out) {
+    mi_clip* m = nullptr;
+    const int rc = guarded([&] {
+        if (!out) fail(MI_ERR_INVALID, "out is null");
+        *out = nullptr;
+        if (!weights_path) fail(MI_ERR_INVALID, "weights_path is null");
+        if (precision != MI_PRECISION_F32) fail(MI_ERR_UNSUPPORTED, "the text tower runs in MI_PRECISION_F32 only");
+        DeviceGuard g(device);
+        m = new mi_clip();
+        m->device = device;
+        m->precision = precision;
+        m->text = true;
+        m->parts = 1;
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        m->n_cu = prop.multiProcessorCount;
+        load_text_weights(m, weights_path);
+        *out = m;
+    });
+    if (rc != MI_OK && m) free_model(m);
+    return rc;
+}
+
+int mi_clip_embed_text(mi_clip* m, const int32_t* input_ids, size_t n, float* out) {
+    return guarded([&] {
+        if (!m) fail(MI_ERR_INVALID, "null model handle");
+        if (!m->text) fail(MI_ERR_INVALID, "this handle holds the image tower: load the text tower with mi_clip_load_text");
+        if (n == 0) return;
+        if (!input_ids || !out) fail(MI_ERR_INVALID, "null buffer");
+        for (size_t i = 0; i < n * (size_t)m->S; ++i)
+            if (input_ids[i] < 0 || input_ids[i] >= m->vocab)
+                fail(MI_ERR_INVALID, "token id %d at position %zu is outside the vocabulary of %d", input_ids[i], i, m->vocab);
+        std::lock_guard<std::mutex> l(m->mu);
+        DeviceGuard g(m->device);
+        const size_t chunk = std::min(n, m->max_batch);
+        ensure_text_workspace(m, chunk);
+        for (size_t i = 0; i < n; i += chunk) {
+            const size_t c = std::min(chunk, n - i);
+            HIP_CHECK(hipMemcpyAsync(m->d_ids, input_ids + i * m->S, c * m->S * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+            forward_text(m, c, m->stream);
+            HIP_CHECK(hipMemcpyAsync(out + i * m->E, m->d_out, c * m->E * 4, hipMemcpyDeviceToHost, m->stream));
+            HIP_CHECK(hipStreamSynchronize(m->stream));
+        }
+    });
+}
+
 int mi_clip_info(const mi_clip* m, uint32_t out[8]) {
     return guarded([&] {
         if (!m || !out) fail(MI_ERR_INVALID, "null argument");
@@ -625,6 +769,7 @@ int mi_clip_info(const mi_clip* m, uint32_t out[8]) {
 int mi_clip_embed_device(mi_clip* m, const float* d_nchw, size_t n, float* d_out, void* stream) {
     return guarded([&] {
         if (!m) fail(MI_ERR_INVALID, "null model handle");
+        if (m->text) fail(MI_ERR_INVALID, "this handle holds the text tower (mi_clip_load_text)");
         if (n == 0) return;
         if (!d_nchw || !d_out) fail(MI_ERR_INVALID, "null buffer");
         std::lock_guard<std::mutex> l(m->mu);
@@ -643,6 +788,7 @@ int mi_clip_embed_device(mi_clip* m, const float* d_nchw, size_t n, float* d_out
 int mi_clip_embed(mi_clip* m, const float* nchw, size_t n, float* out) {
     return guarded([&] {
         if (!m) fail(MI_ERR_INVALID, "null model handle");
+        if (m->text) fail(MI_ERR_INVALID, "this handle holds the text tower (mi_clip_load_text)");
         if (n == 0) return;  // the reference forwards an empty chunk (server/src/clip.rs:112-118)
         if (!nchw || !out) fail(MI_ERR_INVALID, "null buffer");
         std::lock_guard<std::mutex> l(m->mu);
@@ -663,6 +809,7 @@ int mi_clip_embed(mi_clip* m, const float* nchw, size_t n, float* out) {
 int mi_clip_embed_rgb8(mi_clip* m, const uint8_t* rgb8, size_t n, float* out) {
     return guarded([&] {
         if (!m) fail(MI_ERR_INVALID, "null model handle");
+        if (m->text) fail(MI_ERR_INVALID, "this handle holds the text tower (mi_clip_load_text)");
         if (n == 0) return;
         if (!rgb8 || !out) fail(MI_ERR_INVALID, "null buffer");
         std::lock_guard<std::mutex> l(m->mu);
@@ -688,6 +835,7 @@ int mi_clip_embed_images(mi_clip* m, const uint8_t* const* rgb8, const uint32_t*
                          size_t n, float* out) {
     return guarded([&] {
         if (!m) fail(MI_ERR_INVALID, "null model handle");
+        if (m->text) fail(MI_ERR_INVALID, "this handle holds the text tower (mi_clip_load_text)");
         if (n == 0) return;
         if (!rgb8 || !widths || !heights || !out) fail(MI_ERR_INVALID, "null buffer");
         size_t max_src = 0, max_tmp = 0;

@@ -234,14 +234,41 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
     r.store(x + (size_t)row * D, lane);
 }
 
-// CLS pool + post-LN + bias-free projection (modeling_clip.py:641-651, :944-950):
+// ------------------------------------------------------------------ text tower front / pooling index
+// x[r][:] = token_embedding[ids[r]] + position_embedding[r % S]   (CLIPTextEmbeddings.forward)
+__global__ void text_embed_kernel(const int* __restrict__ ids, const float* __restrict__ tok,
+                                  const float* __restrict__ pos, float* __restrict__ x, size_t rows, int S, int D) {
+    const size_t total = rows * (size_t)(D / 4);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (D / 4);
+        const int c = (int)(i % (D / 4)) * 4;
+        const v4f a = *reinterpret_cast<const v4f*>(tok + (size_t)ids[r] * D + c);
+        const v4f b = *reinterpret_cast<const v4f*>(pos + (size_t)(r % S) * D + c);
+        *reinterpret_cast<v4f*>(x + r * D + c) = a + b;
+    }
+}
+// row_of[i] = i*S + argmax_j ids[i][j] (first maximum): the EOS token is the largest id
+__global__ void text_eos_rows_kernel(const int* __restrict__ ids, int n, int S, int* __restrict__ row_of) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int best = 0, bv = ids[(size_t)i * S];
+    for (int j = 1; j < S; ++j) {
+        const int v = ids[(size_t)i * S + j];
+        if (v > bv) { bv = v; best = j; }
+    }
+    row_of[i] = i * S + best;
+}
+
+// Pooled row + post-LN + bias-free projection (vision: modeling_clip.py:641-651, :944-950; text: the
+// EOS row through final_layer_norm and text_projection):
 // out[b][e] = sum_d proj[e][d] * LN_post(x[b*S] (+ d1 + d2))[d], all fp32.  One block per 8 images:
 // their pooled rows sit in LDS and every projection row is fetched once per block, not per image.
 template <int VEC, int NT>
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const bf16_t* __restrict__ delta,
                                                    const bf16_t* __restrict__ delta2, const float* __restrict__ w,
                                                    const float* __restrict__ b, const float* __restrict__ proj,
-                                                   float* __restrict__ out, int n, int S, int E, float eps) {
+                                                   float* __restrict__ out, int n, int S, int E, float eps,
+                                                   const int* __restrict__ row_of) {
     constexpr int D = 64 * VEC * NT, IMG = 8;
     __shared__ float pooled[IMG][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -250,9 +277,10 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
         const int img = img0 + i;
         LnRow<VEC, NT> r;
         if (img < n) {
-            r.load(x + (size_t)img * S * D, lane);
-            if (delta) r.add_bf16(delta + (size_t)img * S * D, lane);
-            if (delta2) r.add_bf16(delta2 + (size_t)img * S * D, lane);
+            const size_t row = row_of ? (size_t)row_of[img] : (size_t)img * S;  // vision: the CLS row; text: the EOS row
+            r.load(x + row * D, lane);
+            if (delta) r.add_bf16(delta + row * D, lane);
+            if (delta2) r.add_bf16(delta2 + row * D, lane);
             r.normalize(w, b, eps, lane);
         } else {
 #pragma unroll
@@ -1371,8 +1399,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persist2_kernel(const bf16_t
 // ------------------------------------------------------------------ attention, fp32 (parity path)
 // softmax(q k^T / 8) v per (image, head), one thread per query row, keys streamed
 // through LDS in chunks of 64, running max / sum (modeling_clip.py:259-277).
+// causal != 0: key j is visible to query i iff j <= i (the text tower's mask).
 __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int S,
-                                                      int D, int H) {
+                                                      int D, int H, int causal) {
     __shared__ __attribute__((aligned(16))) float Ks[64][64];
     __shared__ __attribute__((aligned(16))) float Vs[64][64];
     const int tid = threadIdx.x;
@@ -1406,7 +1435,8 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
             *reinterpret_cast<v4f*>(&Vs[row][c4]) = vv;
         }
         __syncthreads();
-        const int nk = min(64, S - k0);
+        int nk = min(64, S - k0);
+        if (causal) nk = min(nk, qc - k0 + 1);  // keys up to the query's own position
         for (int j = 0; j < nk; ++j) {
             float s = 0.0f;
 #pragma unroll

@@ -149,7 +149,72 @@ class VitConfig:
         return specs
 
 
-def vit_weights(cfg: VitConfig, seed: int = 0) -> dict:
+class TextConfig:
+    """Shape of the CLIP text tower + projection the reference reaches through embed_anything
+    (`Embedder::from_pretrained_hf("Clip", "openai/clip-vit-large-patch14")`, server/src/clip.rs:35-40;
+    used by `clip()`, :19-23).  `clip_l14()` is that model's text side; `tiny()` a unit-test size."""
+
+    def __init__(self, hidden=768, layers=12, heads=12, ff=3072, vocab=49408, positions=77, proj=768, eps=1e-5):
+        self.hidden, self.layers, self.heads, self.ff = hidden, layers, heads, ff
+        self.vocab, self.positions, self.proj, self.eps = vocab, positions, proj, eps
+        assert hidden % heads == 0
+        self.head_dim = hidden // heads
+        self.tokens = positions
+
+    @staticmethod
+    def clip_l14():
+        return TextConfig()
+
+    @staticmethod
+    def tiny():
+        return TextConfig(hidden=128, layers=2, heads=2, ff=512, vocab=1000, positions=20, proj=64)
+
+    def tensor_specs(self):
+        D, L, FF, E = self.hidden, self.layers, self.ff, self.proj
+        in_std = D ** -0.5 * (2 * L) ** -0.5
+        out_std = D ** -0.5
+        fc_std = (2 * D) ** -0.5
+        t = "text_model."
+        specs = [
+            (t + "embeddings.token_embedding.weight", (self.vocab, D), 0.02, 0.0),
+            (t + "embeddings.position_embedding.weight", (self.positions, D), 0.01, 0.0),
+        ]
+        for i in range(L):
+            p = f"{t}encoder.layers.{i}."
+            specs += [
+                (p + "layer_norm1.weight", (D,), 0.05, 1.0), (p + "layer_norm1.bias", (D,), 0.02, 0.0),
+                (p + "self_attn.q_proj.weight", (D, D), in_std, 0.0), (p + "self_attn.q_proj.bias", (D,), 0.02, 0.0),
+                (p + "self_attn.k_proj.weight", (D, D), in_std, 0.0), (p + "self_attn.k_proj.bias", (D,), 0.02, 0.0),
+                (p + "self_attn.v_proj.weight", (D, D), in_std, 0.0), (p + "self_attn.v_proj.bias", (D,), 0.02, 0.0),
+                (p + "self_attn.out_proj.weight", (D, D), out_std, 0.0), (p + "self_attn.out_proj.bias", (D,), 0.02, 0.0),
+                (p + "layer_norm2.weight", (D,), 0.05, 1.0), (p + "layer_norm2.bias", (D,), 0.02, 0.0),
+                (p + "mlp.fc1.weight", (FF, D), fc_std, 0.0), (p + "mlp.fc1.bias", (FF,), 0.02, 0.0),
+                (p + "mlp.fc2.weight", (D, FF), in_std, 0.0), (p + "mlp.fc2.bias", (D,), 0.02, 0.0),
+            ]
+        specs += [
+            (t + "final_layer_norm.weight", (D,), 0.05, 1.0),
+            (t + "final_layer_norm.bias", (D,), 0.02, 0.0),
+            ("text_projection.weight", (E, D), D ** -0.5, 0.0),
+        ]
+        return specs
+
+
+def token_ids(cfg: TextConfig, seed: int, n: int) -> np.ndarray:
+    """n seeded token sequences [n, positions] int32 shaped like a CLIP tokenizer's output:
+    BOS (vocab-2), a random number of word tokens, EOS (vocab-1, the largest id, so that
+    `argmax` finds it — modeling_clip.py's eos_token_id == 2 branch), EOS padding."""
+    with np.errstate(over="ignore"):
+        key = _mix64(np.array([seed ^ 0x7E87], dtype=np.uint64) + _GOLDEN)[0]
+        r = _mix64(np.arange(n * (cfg.positions + 1), dtype=np.uint64) + key).reshape(n, cfg.positions + 1)
+    ids = np.full((n, cfg.positions), cfg.vocab - 1, np.int32)
+    ids[:, 0] = cfg.vocab - 2
+    for i in range(n):
+        words = 1 + int(r[i, 0] % np.uint64(cfg.positions - 2))
+        ids[i, 1:1 + words] = (r[i, 1:1 + words] % np.uint64(cfg.vocab - 2)).astype(np.int32)
+    return ids
+
+
+def vit_weights(cfg, seed: int = 0) -> dict:
     """Seed-reproducible weights: tensor t of the spec list is stream seed*4096+t."""
     out = {}
     for t, (name, shape, std, offset) in enumerate(cfg.tensor_specs()):

@@ -115,6 +115,16 @@ int mi_image_prepare_resnet(int device, const uint8_t* rgb8, uint32_t width, uin
 int mi_clip_embed_images(mi_clip* m, const uint8_t* const* rgb8, const uint32_t* widths, const uint32_t* heights,
                          size_t n, float* out);
 
+/* The text tower of the same model (HF `CLIPTextModelWithProjection` tensors in the safetensors
+ * file): what `clip(state, text)` gets from embed_anything (server/src/clip.rs:19-23, :35-40) and
+ * feeds to the refine step / kNN as the query.  Tokenisation stays with the caller:
+ * input_ids = [n][positions] int32 (BOS .. EOS, padded; positions = mi_clip_info()[2], 77 for CLIP),
+ * the pooled row is the one holding the largest id (the EOS token), as in OpenAI CLIP / candle.
+ * out = [n, 768] f32, not normalised.  MI_PRECISION_F32 only (one query is latency-bound).
+ * The handle is freed with mi_clip_free; the image entry points reject it and vice versa. */
+int mi_clip_load_text(const char* weights_path, int device, int precision, mi_clip** out);
+int mi_clip_embed_text(mi_clip* m, const int32_t* input_ids, size_t n, float* out);
+
 /* ---------------------------------------------------------------- Seam B: kNN */
 
 /* One shard of table `image{embedding}` (server/src/search.rs:13-18; index DDL

@@ -64,6 +64,39 @@ def vit_golden(cfg, name, n_img, seed):
                         embeds_f64=emb_64.astype(np.float64))
 
 
+def hf_text_forward(cfg, weights, ids):
+    import torch
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    hc = CLIPTextConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, intermediate_size=cfg.ff,
+                        num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                        max_position_embeddings=cfg.positions, projection_dim=cfg.proj, hidden_act="quick_gelu",
+                        layer_norm_eps=cfg.eps, eos_token_id=2, bos_token_id=0, pad_token_id=1)  # eos 2: the argmax rule
+    hc._attn_implementation = "eager"
+    m = CLIPTextModelWithProjection(hc).eval()
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in weights.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if "position_ids" not in k]
+    assert not missing and not unexpected, (missing, unexpected)
+    with torch.no_grad():
+        out = m(input_ids=torch.from_numpy(ids.astype(np.int64)))
+    return out.text_embeds.numpy()
+
+
+def text_golden(cfg, name, n_seq, seed):
+    """The text tower (server/src/clip.rs:19-23): transformers'
+    CLIPTextModelWithProjection on seeded weights pins oracle/vit_numpy.py:text_forward."""
+    w = synth.vit_weights(cfg, seed)
+    ids = synth.token_ids(cfg, seed + 7, n_seq)
+    emb_hf = hf_text_forward(cfg, w, ids)
+    emb_np = vit_numpy.text_forward(w, cfg, ids, np.float32)
+    emb_64 = vit_numpy.text_forward(w, cfg, ids, np.float64)
+    rms = float(np.sqrt((emb_64 ** 2).mean()))
+    print(f"[text {name}] rms={rms:.4f}  |hf-f64|max={np.abs(emb_hf - emb_64).max():.3e}  "
+          f"|np32-f64|max={np.abs(emb_np - emb_64).max():.3e}  |hf-np32|max={np.abs(emb_hf - emb_np).max():.3e}")
+    np.savez_compressed(os.path.join(GOLD, f"text_{name}.npz"), seed=seed, n_seq=n_seq, ids_seed=seed + 7,
+                        embeds_hf_f32=emb_hf.astype(np.float32), embeds_f64=emb_64.astype(np.float64))
+
+
 def knn_golden():
     lib = load_oracle()
     cases = {}
@@ -131,5 +164,7 @@ if __name__ == "__main__":
     resize_golden()
     knn_golden()
     vit_golden(synth.VitConfig.tiny(), "tiny", 3, 1)
+    text_golden(synth.TextConfig.tiny(), "tiny", 4, 2)
     if a.full:
         vit_golden(synth.VitConfig.vit_l14(), "l14", 2, 0)
+        text_golden(synth.TextConfig.clip_l14(), "l14", 3, 3)

@@ -35,6 +35,38 @@ def _quick_gelu(x):
     return x / (x.dtype.type(1) + np.exp(x.dtype.type(-1.702) * x))
 
 
+def _encoder(h, W, prefix, cfg, dtype, causal=False):
+    """modeling_clip.py:353-383 x layers: pre-LN residual blocks; `causal` adds the text tower's
+    mask (modeling_clip.py: _create_4d_causal_attention_mask — key j visible to query i iff j <= i)."""
+    n, S, D = h.shape
+    H, dh = cfg.heads, cfg.head_dim
+    scale = dtype(dh ** -0.5)
+    for i in range(cfg.layers):
+        p = f"{prefix}encoder.layers.{i}."
+        y = _layer_norm(h, W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], cfg.eps)
+        # modeling_clip.py:280-335 — q/k/v/out projections with bias
+        q = y @ W[p + "self_attn.q_proj.weight"].T + W[p + "self_attn.q_proj.bias"]
+        k = y @ W[p + "self_attn.k_proj.weight"].T + W[p + "self_attn.k_proj.bias"]
+        vv = y @ W[p + "self_attn.v_proj.weight"].T + W[p + "self_attn.v_proj.bias"]
+        q = q.reshape(n, S, H, dh).transpose(0, 2, 1, 3)
+        k = k.reshape(n, S, H, dh).transpose(0, 2, 1, 3)
+        vv = vv.reshape(n, S, H, dh).transpose(0, 2, 1, 3)
+        # modeling_clip.py:259-277 — softmax(q k^T * scale) v, softmax in fp32
+        s = (q @ k.transpose(0, 1, 3, 2)) * scale
+        if causal:
+            s = np.where(np.tril(np.ones((S, S), bool)), s, dtype(-np.inf))
+        s = s - s.max(axis=-1, keepdims=True)
+        e = np.exp(s)
+        a = e / e.sum(axis=-1, keepdims=True, dtype=dtype)
+        ctx = (a @ vv).transpose(0, 2, 1, 3).reshape(n, S, D)
+        h = h + (ctx @ W[p + "self_attn.out_proj.weight"].T + W[p + "self_attn.out_proj.bias"])
+        y = _layer_norm(h, W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], cfg.eps)
+        # modeling_clip.py:338-350 — fc1 -> QuickGELU -> fc2
+        y = _quick_gelu(y @ W[p + "mlp.fc1.weight"].T + W[p + "mlp.fc1.bias"])
+        h = h + (y @ W[p + "mlp.fc2.weight"].T + W[p + "mlp.fc2.bias"])
+    return h
+
+
 def vit_forward(weights: dict, cfg, pixels: np.ndarray, dtype=np.float32, return_hidden=False):
     """pixels [n,3,H,W] -> image_embeds [n,proj].  dtype float32 is the parity
     oracle; float64 gives the real-number answer used to size the noise floor."""
@@ -51,33 +83,28 @@ def vit_forward(weights: dict, cfg, pixels: np.ndarray, dtype=np.float32, return
     h = np.concatenate([cls, pe], axis=1) + W[v + "embeddings.position_embedding.weight"]
     # modeling_clip.py:641-651 — pre_layrnorm -> encoder -> CLS -> post_layernorm
     h = _layer_norm(h, W[v + "pre_layrnorm.weight"], W[v + "pre_layrnorm.bias"], cfg.eps)
-    scale = dtype(dh ** -0.5)
-    for i in range(cfg.layers):
-        p = f"{v}encoder.layers.{i}."
-        # modeling_clip.py:353-383 — pre-LN residual block
-        y = _layer_norm(h, W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], cfg.eps)
-        # modeling_clip.py:280-335 — q/k/v/out projections with bias
-        q = y @ W[p + "self_attn.q_proj.weight"].T + W[p + "self_attn.q_proj.bias"]
-        k = y @ W[p + "self_attn.k_proj.weight"].T + W[p + "self_attn.k_proj.bias"]
-        vv = y @ W[p + "self_attn.v_proj.weight"].T + W[p + "self_attn.v_proj.bias"]
-        S = q.shape[1]
-        q = q.reshape(n, S, H, dh).transpose(0, 2, 1, 3)
-        k = k.reshape(n, S, H, dh).transpose(0, 2, 1, 3)
-        vv = vv.reshape(n, S, H, dh).transpose(0, 2, 1, 3)
-        # modeling_clip.py:259-277 — softmax(q k^T * scale) v, softmax in fp32
-        s = (q @ k.transpose(0, 1, 3, 2)) * scale
-        s = s - s.max(axis=-1, keepdims=True)
-        e = np.exp(s)
-        a = e / e.sum(axis=-1, keepdims=True, dtype=dtype)
-        ctx = (a @ vv).transpose(0, 2, 1, 3).reshape(n, S, D)
-        h = h + (ctx @ W[p + "self_attn.out_proj.weight"].T + W[p + "self_attn.out_proj.bias"])
-        y = _layer_norm(h, W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], cfg.eps)
-        # modeling_clip.py:338-350 — fc1 -> QuickGELU -> fc2
-        y = _quick_gelu(y @ W[p + "mlp.fc1.weight"].T + W[p + "mlp.fc1.bias"])
-        h = h + (y @ W[p + "mlp.fc2.weight"].T + W[p + "mlp.fc2.bias"])
+    h = _encoder(h, W, v, cfg, dtype)
     pooled = _layer_norm(h[:, 0, :], W[v + "post_layernorm.weight"], W[v + "post_layernorm.bias"], cfg.eps)
     # modeling_clip.py:944-950 — bias-free projection
     out = pooled @ W["visual_projection.weight"].T
     if return_hidden:
         return out, h
     return out
+
+
+def text_forward(weights: dict, cfg, input_ids: np.ndarray, dtype=np.float32):
+    """input_ids [n,positions] int -> text_embeds [n,proj]: the CLIP text tower the reference
+    calls through embed_anything (server/src/clip.rs:19-23, :35-40), restated from
+    modeling_clip.py (CLIPTextTransformer / CLIPTextModelWithProjection): token + position
+    embeddings, causal pre-LN encoder, final LayerNorm, the row of the EOS token — located as
+    `input_ids.argmax(-1)`, OpenAI's and candle's rule (EOS is the largest id) — and the
+    bias-free text projection.  No L2 normalisation (server/src/clip.rs:22 takes the dense vector as is)."""
+    W = {k: v.astype(dtype) for k, v in weights.items()}
+    t = "text_model."
+    ids = np.asarray(input_ids)
+    n, S = ids.shape
+    h = W[t + "embeddings.token_embedding.weight"][ids] + W[t + "embeddings.position_embedding.weight"][:S]
+    h = _encoder(h, W, t, cfg, dtype, causal=True)
+    h = _layer_norm(h, W[t + "final_layer_norm.weight"], W[t + "final_layer_norm.bias"], cfg.eps)
+    pooled = h[np.arange(n), ids.argmax(axis=-1)]
+    return pooled @ W["text_projection.weight"].T

@@ -217,3 +217,53 @@ def test_load_errors_are_codes(built, mi, tmp_path):
     synth.save_safetensors(w, p)
     with pytest.raises(MiError, match="visual_projection.weight"):
         Model.from_file(p, 0, 0)
+
+
+# ---- text tower (server/src/clip.rs:19-23) ---------------------------------
+
+from image_search_amd.clip import TextModel
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny", synth.TextConfig.tiny()), ("l14", synth.TextConfig.clip_l14())])
+def test_text_tower_fp32_matches_transformers_golden_and_oracle(built, tmp_path, name, cfg):
+    g = np.load(os.path.join(GOLDEN, f"text_{name}.npz"))
+    w = synth.vit_weights(cfg, int(g["seed"]))
+    path = str(tmp_path / "text.safetensors")
+    synth.save_safetensors(w, path, {"num_attention_heads": cfg.heads})
+    ids = synth.token_ids(cfg, int(g["ids_seed"]), int(g["n_seq"]))
+    m = TextModel.from_file(path)
+    assert (m.positions, m.hidden, m.layers, m.proj) == (cfg.positions, cfg.hidden, cfg.layers, cfg.proj)
+    out = m.embed(ids)
+    ok, err = close(out, g["embeds_hf_f32"], 1e-4)           # transformers CLIPTextModelWithProjection
+    assert ok, err
+    ok, err = close(out, g["embeds_f64"], 1e-4)
+    assert ok, err
+    ok, err = close(out, vit_numpy.text_forward(w, cfg, ids, np.float32), 1e-4)
+    assert ok, err
+    # causality: tokens after the EOS do not change the pooled embedding; more sequences than one pass
+    ids2 = ids.copy()
+    for i in range(ids2.shape[0]):
+        e = int(ids2[i].argmax())
+        ids2[i, e + 1:] = 0
+    assert np.array_equal(m.embed(ids2), out)
+    assert m.embed(ids[:0]).shape == (0, cfg.proj)
+    many = np.concatenate([ids] * 3)
+    assert np.array_equal(m.embed(many)[-ids.shape[0]:], out)
+
+
+def test_text_tower_errors_are_codes(built, tmp_path):
+    cfg = synth.TextConfig.tiny()
+    path = str(tmp_path / "text.safetensors")
+    synth.save_safetensors(synth.vit_weights(cfg, 2), path, {"num_attention_heads": cfg.heads})
+    m = TextModel.from_file(path)
+    bad = synth.token_ids(cfg, 1, 2)
+    bad[1, 3] = cfg.vocab
+    with pytest.raises(MiError) as e:
+        m.embed(bad)
+    assert e.value.code == -1
+    from image_search_amd._lib import c_vp, lib
+    h = c_vp()
+    assert lib().mi_clip_load_text(path.encode(), 0, PRECISION_BF16, ctypes.byref(h)) == -5       # fp32 only
+    assert lib().mi_clip_load(path.encode(), 0, PRECISION_F32, ctypes.byref(h)) != 0             # no vision tensors in the file
+    out = np.zeros((1, cfg.proj), np.float32)
+    assert lib().mi_clip_embed(m._h, out.ctypes.data, 1, out.ctypes.data) == -1                   # image entry point, text handle
