@@ -419,8 +419,12 @@ void gemm_p(int precision, const void* X, const void* W, const float* bias, void
     if (N % 128 != 0) fail(MI_ERR_UNSUPPORTED, "GEMM N=%d is not a multiple of 128", N);
     if (precision == MI_PRECISION_F32) {
         if (K % 16 != 0) fail(MI_ERR_UNSUPPORTED, "GEMM K=%d is not a multiple of 16", K);
-        hipLaunchKernelGGL((gemm_f32_kernel<EPI>), dim3(blocks), dim3(256), 0, s, (const float*)X, (const float*)W, bias,
-                           (float*)out, N, K, ldo);
+        if (Mp == 128)  // a handful of rows (text queries): 4x more, narrower workgroups
+            hipLaunchKernelGGL((gemm_f32_n32_kernel<EPI>), dim3((unsigned)(N / 32)), dim3(256), 0, s, (const float*)X, (const float*)W,
+                               bias, (float*)out, N, K, ldo);
+        else
+            hipLaunchKernelGGL((gemm_f32_kernel<EPI>), dim3(blocks), dim3(256), 0, s, (const float*)X, (const float*)W, bias,
+                               (float*)out, N, K, ldo);
     } else {
         if (K % 64 != 0) fail(MI_ERR_UNSUPPORTED, "GEMM K=%d is not a multiple of 64", K);
         static bool attr_done[4] = {false, false, false, false};

@@ -424,6 +424,61 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             }
 }
 
+// fp32 GEMM for a handful of rows (the text tower: one query = 77 token rows): the same arithmetic on
+// 128 x 32 tiles, so that N/32 instead of N/128 workgroups share the work (4 waves = 4 row blocks of 32).
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_n32_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int N, int K, int ldo) {
+    constexpr int LDT = 132;
+    __shared__ float Xs[2][16][LDT];
+    __shared__ float Ws[2][16][36];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int nt = N / 32;
+    const int tm = blockIdx.x / nt, tn = blockIdx.x % nt;
+    const size_t m0 = (size_t)tm * 128;
+    const int n0 = tn * 32;
+    const int r = tid >> 2, kq = tid & 3;
+    const float* xp = X + (m0 + r) * K + 4 * kq;
+    const float* wp = W + ((size_t)n0 + (r & 31)) * K + 4 * kq;
+    v4f rx0, rx1, rw0;
+    auto gload = [&](int kt) {
+        rx0 = *reinterpret_cast<const v4f*>(xp + kt * 16);
+        rx1 = *reinterpret_cast<const v4f*>(xp + (size_t)64 * K + kt * 16);
+        if (r < 32) rw0 = *reinterpret_cast<const v4f*>(wp + kt * 16);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            Xs[buf][4 * kq + c][r] = rx0[c]; Xs[buf][4 * kq + c][r + 64] = rx1[c];
+            if (r < 32) Ws[buf][4 * kq + c][r] = rw0[c];
+        }
+    };
+    v16f acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    const int nk = K / 16;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[cur][2 * kk + h][l31], Xs[cur][2 * kk + h][wave * 32 + l31], acc, 0, 0, 0);
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v4f v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        epilogue4<EPI, float, false>(v, bias, out, m0 + wave * 32 + l31, n0 + 8 * q + 4 * h, ldo);
+    }
+}
+
 // ------------------------------------------------------------------ bf16 GEMM (throughput path)
 // 128x128x64 tiles, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles.
 // Both operand tiles go HBM -> LDS with global_load_lds_dwordx4 (1 KiB = 8 rows of
