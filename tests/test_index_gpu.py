@@ -83,3 +83,32 @@ def test_scan_loop_embeds_new_files_once(built, orc, tmp_path):
     for row, p in enumerate(ix.paths):                                                  # each row is its own file's embedding
         px = synth.preprocess_rgb8(orc_resize_catmullrom(orc, imgs[p], m.image, m.image)[None])
         assert np.array_equal(ix.table.rows(row, 1), m.forward(px))
+
+
+def test_end_to_end_text_query_over_scanned_directory(built, tmp_path):
+    """The reference's whole request path on the device: scan a media directory (decode -> resize ->
+    tower -> rows), then `web_search_text`: text tower -> refine with a marked image -> kNN -> paths.
+    Checked against the same flow assembled from the parts that are individually pinned."""
+    from PIL import Image
+    from image_search_amd.clip import TextModel
+    vcfg, tcfg = synth.VitConfig.tiny(), synth.TextConfig.tiny()
+    assert vcfg.proj == tcfg.proj
+    vpath, tpath = str(tmp_path / "v.safetensors"), str(tmp_path / "t.safetensors")
+    synth.save_safetensors(synth.vit_weights(vcfg, 1), vpath, {"num_attention_heads": vcfg.heads})
+    synth.save_safetensors(synth.vit_weights(tcfg, 2), tpath, {"num_attention_heads": tcfg.heads})
+    vm, tm = Model.from_file(vpath, 0, PRECISION_F32), TextModel.from_file(tpath)
+    media = tmp_path / "media"
+    media.mkdir()
+    for i in range(12):
+        Image.fromarray(synth.photo_u8(60 + i, 40 + 7 * i, 90 - 3 * i)).save(media / f"p{i:02d}.png")
+    ix = ImageIndex(vcfg.proj, 0, str(media) + "/")
+    assert embed_all_images_in_dir(vm, ix, str(media), image_chunk_size=5, shuffle_seed=3) == 12
+    text = tm.embed(synth.token_ids(tcfg, 5, 1))[0]
+    marked = "media/p03.png"
+    got = ix.web_search_text(text, [marked], k=5)
+    row = ix.paths.index(str(media / "p03.png"))
+    q = refine_query(text, [ix.table.rows(row, 1)[0]])
+    ids, dist = ix.table.knn(q, 5)
+    assert [g[0] for g in got] == [int(i) for i in ids]
+    assert all(g[1].startswith("media/p") for g in got)
+    assert np.array_equal(np.array([g[2] for g in got], np.float32), dist)

@@ -63,7 +63,16 @@ int main(int argc, char** argv) {
         CK(hipMemset(O2, 0, M * s.N * 2));
         float t4 = time_ms(kper, 10);
         CK(hipMemset(O2, 0, M * s.N * 2));
-        float t5 = argc > 1 ? time_ms(kper, 10) : time_ms(kper2, 10);  // with an argument: the compared output is the first persistent kernel's
+        float t5 = time_ms(kper2, 10);
+        // race screen: argv[1] repetitions of {clear, run once, compare with the 128x128 kernel's output}
+        for (int rep = 0; rep < (argc > 1 ? atoi(argv[1]) : 0); ++rep) {
+            CK(hipMemset(O2, 0xff, M * s.N * 2));
+            kper2();
+            CK(hipMemset(d, 0, 4));
+            hipLaunchKernelGGL(maxdiff, 1024, 256, 0, 0, O1, O2, M * s.N, d);
+            float mdr; CK(hipMemcpy(&mdr, d, 4, hipMemcpyDeviceToHost));
+            if (mdr != 0.0f) printf("   RACE SCREEN: repetition %d of %s differs from the reference kernel (max diff %g)\n", rep, s.name, mdr);
+        }
         CK(hipMemset(d, 0, 4));
         hipLaunchKernelGGL(maxdiff, 1024, 256, 0, 0, O1, O2, M * s.N, d);
         float md; CK(hipMemcpy(&md, d, 4, hipMemcpyDeviceToHost));
