@@ -454,15 +454,12 @@ void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out
             constexpr int LDS = 131072 + 18432 + 2048;
             // Default (3): two wave groups one barrier apart (gemm_bf16_pp_kernel, 214 VGPRs): -12 % per
             // GEMM alone, 46.9 vs 49.9 ms per 256 images in the tower.  MI_GEMM_V=1: the one-barrier form
-            // (186 VGPRs), =2: its fragment-prefetch variant (254 VGPRs, K/64 even) -- kept for A/B.
+            // (186 VGPRs), kept for A/B.
             static const int ver = std::getenv("MI_GEMM_V") ? std::atoi(std::getenv("MI_GEMM_V")) : 3;
-            auto kern = (ver == 2 && (K / 64) % 2 == 0) ? gemm_bf16_persist2_kernel<EPI, bf16_t>
-                        : ver == 3                        ? gemm_bf16_pp_kernel<EPI, bf16_t>
-                                                          : gemm_bf16_persist_kernel<EPI, bf16_t>;
+            auto kern = ver == 1 ? gemm_bf16_persist_kernel<EPI, bf16_t> : gemm_bf16_pp_kernel<EPI, bf16_t>;
             static bool done = false;
             if (!done) {
                 HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-                HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_persist2_kernel<EPI, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
                 HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<EPI, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
                 done = true;
             }

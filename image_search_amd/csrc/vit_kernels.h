@@ -1170,287 +1170,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
 #undef PP_BAR
 }
 
-// ------------------------------------------------------------------ bf16 GEMM, persistent, fragment prefetch
-// gemm_bf16_persist_kernel with the LDS latency taken off the critical path: the fragments a
-// phase multiplies were fetched during the PREVIOUS phase (two X and two W fragment sets), so a
-// phase is {counted wait + barrier for the NEXT phase's half-tile, issue one half-tile of the
-// stream five phases ahead, ds_read the next phase's fragments, 16 MFMAs on registers}.  Each
-// fragment is read from LDS exactly once per K tile (24 ds_read_b128 per 64 MFMAs).
-//   per K tile:  P0 reads W1  | P1 reads X1 | P2 reads nothing | P3 reads X0', W0' of the next K tile
-//   waits:       P0, P1, P3 (vmcnt(4): two half-tiles stay in flight); 3 barriers per K tile
-// The W fragment sets swap roles every K tile, so the loop body is two K tiles (K/64 must be even).
-template <int EPI, typename TO>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_persist2_kernel(const bf16_t* __restrict__ X,
-                                                                    const bf16_t* __restrict__ W,
-                                                                    const float* __restrict__ bias,
-                                                                    void* __restrict__ out, int M, int N, int K,
-                                                                    int ldo, int n_tiles, int n_full, int l2_order) {
-    static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU, "the persistent form stores bf16 with bias");
-    static_assert(sizeof(TO) == 2, "bf16 output");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 128 KiB staging + 18 KiB patches + 2 KiB bias
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3, g = lane >> 4, l15 = lane & 15;
-    const int nt = N / 256;
-    const int G = gridDim.x;
-    const int lb = (int)xcd_remap(blockIdx.x, G);
-    int tile = lb;
-
-    const uint32_t Kb = (uint32_t)K * 2;
-    const rsrc_t xr = make_rsrc(X, (uint32_t)M * Kb);
-    const rsrc_t wr = make_rsrc(W, (uint32_t)N * Kb);
-    const rsrc_t orr = make_rsrc(out, (uint32_t)M * (uint32_t)ldo * 2u);
-    const rsrc_t br = make_rsrc(bias, (uint32_t)N * 4u);
-    const int rr = lane >> 3, p = lane & 7;
-    const uint32_t x_lane = (uint32_t)rr * Kb + 16 * (p ^ rr);
-    const uint32_t x_wave = (uint32_t)(128 * (wave >> 2) + 16 * (wave & 3)) * Kb;
-    const uint32_t w_wave = (uint32_t)(64 * (wave >> 1) + 16 * (wave & 1)) * Kb;
-    auto stage_half = [&](int buf, uint32_t xs, uint32_t ws, int kt, int i) {
-        const bool is_x = (i == 0 || i == 3);
-        const int h = (i >= 2) ? 1 : 0;
-        unsigned char* dst = smem + buf * 65536 + (is_x ? 0 : 32768) + h * 16384 + wave * 2048;
-        const uint32_t so = (is_x ? xs + x_wave + 64u * h * Kb : ws + w_wave + 32u * h * Kb) + (uint32_t)kt * 128u;
-        glds16_buf(is_x ? xr : wr, x_lane, so, dst);
-        glds16_buf(is_x ? xr : wr, x_lane, so + 8u * Kb, dst + 1024);
-    };
-    unsigned char* bias_lds = smem + 131072 + 18432 + wave * 256;
-    auto stage_bias = [&](int tn) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (__attribute__((address_space(3))) void*)bias_lds, 4,
-                                                 (uint32_t)lane * 4u, (uint32_t)(tn * 256 + wn * 64) * 4u, 0, 0);
-    };
-
-    const int sw = lane & 7;
-    const int x_off = (wm * 64 + l15) * 128;
-    const int w_off = 32768 + (wn * 32 + l15) * 128;
-    bf16x8 xfA[2][4], xfB[2][4], wfA[2][2], wfB[2][2];
-    v4f acc[4][8];
-    // LDS read addresses: four VGPRs (X / W x k-step 0 / 1) that always point into the buffer being
-    // read; everything else of a fragment address is an immediate.  MI_FLIP moves them to the other
-    // buffer (before the reads of the next K tile's first fragments in P3).
-    typedef const __attribute__((address_space(3))) bf16x8* lds_frag_t;
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    uint32_t xa[2], wa[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        xa[ks] = lds0 + (uint32_t)x_off + ((uint32_t)((4 * ks + g) ^ sw) << 4);
-        wa[ks] = lds0 + (uint32_t)w_off + ((uint32_t)((4 * ks + g) ^ sw) << 4);
-    }
-#define MI_LOAD_X(DST, MH)                                                                                     \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                           \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
-        DST[ks][i] = *(lds_frag_t)(size_t)(xa[ks] + (uint32_t)((MH) * 16384 + i * 2048));
-#define MI_LOAD_W(DST, NH)                                                                                     \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                           \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                              \
-        DST[ks][i] = *(lds_frag_t)(size_t)(wa[ks] + (uint32_t)((NH) * 16384 + i * 2048));
-#define MI_FLIP                                                                                                \
-    { const uint32_t d = b ? (uint32_t)-65536 : 65536u; xa[0] += d; xa[1] += d; wa[0] += d; wa[1] += d; }
-#define MI_QUADRANT(XF, WF, MH, NH)                                                                       \
-    __builtin_amdgcn_s_setprio(1);                                                                        \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
-    _Pragma("unroll") for (int im = 0; im < 4; ++im)                                                      \
-    _Pragma("unroll") for (int in = 0; in < 2; ++in)                                                      \
-        acc[2 * NH + in][4 * MH + im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
-            WF[ks][in], XF[ks][im], acc[2 * NH + in][4 * MH + im], 0, 0, 0);                               \
-    __builtin_amdgcn_s_setprio(0);
-// wave-uniform wait + barrier in front of the reads of phase PH (0, 1 or 3)
-//   mode 0 steady state: two half-tiles stay in flight
-//   mode 1 first K tile after an epilogue: 16 stores + 1 bias DMA were issued in between (PH 0, 1)
-//   mode 2 last K tile of this workgroup's stream: (2, 0)
-#define MI_SYNC(PH)                                                                                               \
-    if (mode == 2) { if (PH == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } \
-    else if (mode == 1 && PH < 2) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");                              \
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                         \
-    __builtin_amdgcn_s_barrier();
-// one 64-deep K tile; X0 is in xfA, W0 in WA; leaves the next K tile's X0 in xfA and W0 in WB
-#define MI_KTILE(WA, WB)                                                                                       \
-    {                                                                                                          \
-        const bool last_kt = (kt == nk - 1);                                                                   \
-        const bool a_in = !last_kt, b_in = kt + 2 < nk;        /* K tile +1 / +2 still inside this tile? */    \
-        const bool stage_a = a_in || has_next, stage_b = b_in || has_next;                                     \
-        const uint32_t sa_x = a_in ? xs : nx, sa_w = a_in ? ws : nw, sb_x = b_in ? xs : nx;                    \
-        const int sa_kt = a_in ? kt + 1 : 0, sb_kt = b_in ? kt + 2 : kt + 2 - nk;                              \
-        const int mode = !stage_a ? 2 : ((after_epilogue && kt == 0) ? 1 : 0);                                 \
-        MI_SYNC(0) if (stage_a) stage_half(b ^ 1, sa_x, sa_w, sa_kt, 1);                                       \
-        MI_LOAD_W(WB, 1) MI_QUADRANT(xfA, WA, 0, 0)                                                            \
-        MI_SYNC(1) if (stage_a) stage_half(b ^ 1, sa_x, sa_w, sa_kt, 2);                                       \
-        MI_LOAD_X(xfB, 1) MI_QUADRANT(xfA, WB, 0, 1)                                                           \
-        if (stage_a) stage_half(b ^ 1, sa_x, sa_w, sa_kt, 3);                                                  \
-        MI_QUADRANT(xfB, WB, 1, 1)                                                                             \
-        MI_FLIP                                                                                                \
-        if (stage_a) {                                                                                         \
-            MI_SYNC(3) if (stage_b) stage_half(b, sb_x, 0u, sb_kt, 0);                                         \
-            MI_LOAD_X(xfA, 0)                                                                                  \
-        }                                                                                                      \
-        MI_QUADRANT(xfB, WA, 1, 0)                                                                             \
-        if (stage_a) { MI_LOAD_W(WB, 0) }                                                                      \
-        b ^= 1; ++kt;                                                                                          \
-    }
-
-    const int nk = K / 64;
-    const int mt = M / 256;
-    int b = 0, kt = 0;
-    TileMN cur = tile_of_visit(tile, G, nt, mt, l2_order ? n_full : -1);
-    uint32_t xs = (uint32_t)cur.tm * 256u * Kb, ws = (uint32_t)cur.tn * 256u * Kb;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[a][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-    if (tile < n_full) {
-    stage_bias(cur.tn);  // oldest op of the stream
-#pragma unroll
-    for (int i = 0; i < 4; ++i) stage_half(0, xs, ws, 0, i);
-    stage_half(1, xs, ws, 1, 0);  // fifth half-tile: XH0 of K tile 1
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    MI_LOAD_X(xfA, 0)
-    MI_LOAD_W(wfA, 0)
-    bool after_epilogue = false;
-    const uint32_t o_lane = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
-    for (;;) {
-        const int next = tile + G;
-        const bool has_next = next < n_full;
-        const TileMN nxt = tile_of_visit(next, G, nt, mt, l2_order ? n_full : -1);
-        const uint32_t nx = (uint32_t)nxt.tm * 256u * Kb, nw = (uint32_t)nxt.tn * 256u * Kb;
-        MI_KTILE(wfA, wfB)
-        MI_KTILE(wfB, wfA)
-        after_epilogue = false;
-        if (kt < nk) continue;
-
-        // epilogue (see gemm_bf16_persist_kernel): 16 row-contiguous stores per lane, left in flight
-        __builtin_amdgcn_sched_barrier(0);
-        const int n0 = cur.tn * 256;
-        const uint32_t o_tile = ((uint32_t)cur.tm * 256u * (uint32_t)ldo + (uint32_t)n0) * 2u;
-        v4f bv[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bv[ni] = *reinterpret_cast<const v4f*>(bias_lds + (ni * 16 + 4 * g) * 4);
-        unsigned char* patch = smem + 131072 + wave * 2304;
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                v4f v = acc[ni][mi] + bv[ni];
-                if constexpr (EPI == EPI_BIAS_QGELU) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = quick_gelu<true>(v[c]);
-                }
-                v2u pk;
-                pk.x = pack2bf(v[0], v[1]);
-                pk.y = pack2bf(v[2], v[3]);
-                *reinterpret_cast<v2u*>(patch + l15 * 144 + (ni * 16 + 4 * g) * 2) = pk;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = j * 8 + (lane >> 3);
-                const v4u d = *reinterpret_cast<const v4u*>(patch + row * 144 + (lane & 7) * 16);
-                const uint32_t so = o_tile + (uint32_t)(mi * 16 + j * 8) * (uint32_t)ldo * 2u;
-                __builtin_amdgcn_raw_buffer_store_b128(d, orr, o_lane, so, 0);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) acc[a][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-        if (!has_next) break;
-        tile = next;
-        cur = nxt;
-        xs = nx; ws = nw;
-        kt = 0;
-        after_epilogue = true;
-        stage_bias(cur.tn);  // one more counted op between the stores and the next K tile
-    }
-    }  // full tiles
-
-    // ---- the last, partial round as quadrant tasks (see gemm_bf16_persist_kernel)
-    // (per-lane constants are re-derived from an opaque copy of the lane id here so that none of
-    //  them stays live across the main loop, which runs at the 256-register limit)
-    const int n_tasks = (n_tiles - n_full) * 4;
-    for (int task = lb; task < n_tasks; task += G) {
-        int lane_t = lane;
-        asm volatile("" : "+v"(lane_t));
-        const int g = lane_t >> 4, l15 = lane_t & 15, sw = lane_t & 7;
-        const int x_off = (wm * 64 + l15) * 128, w_off = 32768 + (wn * 32 + l15) * 128;
-        const uint32_t x_lane = (uint32_t)(lane_t >> 3) * Kb + 16 * ((lane_t & 7) ^ (lane_t >> 3));
-        auto stage_half = [&](int buf, uint32_t xs_, uint32_t ws_, int kt_, int i) {
-            const bool is_x = (i == 0 || i == 3);
-            const int h = (i >= 2) ? 1 : 0;
-            unsigned char* dst = smem + buf * 65536 + (is_x ? 0 : 32768) + h * 16384 + wave * 2048;
-            const uint32_t so = (is_x ? xs_ + x_wave + 64u * h * Kb : ws_ + w_wave + 32u * h * Kb) + (uint32_t)kt_ * 128u;
-            glds16_buf(is_x ? xr : wr, x_lane, so, dst);
-            glds16_buf(is_x ? xr : wr, x_lane, so + 8u * Kb, dst + 1024);
-        };
-        auto stage_bias = [&](int tn_) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (__attribute__((address_space(3))) void*)bias_lds, 4,
-                                                     (uint32_t)lane_t * 4u, (uint32_t)(tn_ * 256 + wn * 64) * 4u, 0, 0);
-        };
-        const int t = n_full + (task >> 2), mh = (task >> 1) & 1, nh = task & 1;
-        const TileMN tt = tile_of_visit(t, G, nt, M / 256, l2_order ? n_full : -1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const uint32_t txs = (uint32_t)tt.tm * 256u * Kb + 64u * mh * Kb, tws = (uint32_t)tt.tn * 256u * Kb + 32u * nh * Kb;
-        stage_bias(tt.tn);
-        stage_half(0, txs, tws, 0, 0); stage_half(0, txs, tws, 0, 1);
-        if (nk > 1) { stage_half(1, txs, tws, 1, 0); stage_half(1, txs, tws, 1, 1); }
-        for (int kq = 0; kq < nk; ++kq) {
-            if (kq + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const uint32_t tb = lds0 + (uint32_t)(kq & 1) * 65536u;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                xa[ks] = tb + (uint32_t)x_off + ((uint32_t)((4 * ks + g) ^ sw) << 4);
-                wa[ks] = tb + (uint32_t)w_off + ((uint32_t)((4 * ks + g) ^ sw) << 4);
-            }
-            MI_LOAD_X(xfA, 0)
-            MI_LOAD_W(wfA, 0)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // every wave has its fragments: the buffer may be refilled
-            if (kq + 2 < nk) { stage_half(kq & 1, txs, tws, kq + 2, 0); stage_half(kq & 1, txs, tws, kq + 2, 1); }
-            MI_QUADRANT(xfA, wfA, 0, 0)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        v4f bq[2];
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) bq[ni] = *reinterpret_cast<const v4f*>(bias_lds + (32 * nh + ni * 16 + 4 * g) * 4);
-        unsigned char* patch = smem + 131072 + wave * 2304;
-        const uint32_t q_tile = ((uint32_t)tt.tm * 256u * (uint32_t)ldo + (uint32_t)(tt.tn * 256)) * 2u;
-        const uint32_t q_lane = ((uint32_t)(wm * 128 + 64 * mh + (lane_t >> 2)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 32 * nh + 8 * (lane_t & 3))) * 2u;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                v4f v = acc[ni][mi] + bq[ni];
-                acc[ni][mi] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-                if constexpr (EPI == EPI_BIAS_QGELU) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = quick_gelu<true>(v[c]);
-                }
-                v2u pk;
-                pk.x = pack2bf(v[0], v[1]);
-                pk.y = pack2bf(v[2], v[3]);
-                *reinterpret_cast<v2u*>(patch + l15 * 144 + (ni * 16 + 4 * g) * 2) = pk;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            const v4u d = *reinterpret_cast<const v4u*>(patch + (lane_t >> 2) * 144 + (lane_t & 3) * 16);
-            __builtin_amdgcn_raw_buffer_store_b128(d, orr, q_lane, q_tile + (uint32_t)(mi * 16) * (uint32_t)ldo * 2u, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#undef MI_LOAD_X
-#undef MI_LOAD_W
-#undef MI_FLIP
-#undef MI_QUADRANT
-#undef MI_SYNC
-#undef MI_KTILE
-}
-
 // ------------------------------------------------------------------ attention, fp32 (parity path)
 // softmax(q k^T / 8) v per (image, head), one thread per query row, keys streamed
 // through LDS in chunks of 64, running max / sum (modeling_clip.py:259-277).
