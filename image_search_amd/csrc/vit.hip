@@ -467,7 +467,8 @@ void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out
             const int grid = std::min(n_tiles * 4, m->n_cu);
             // a short last round (<= a quarter of the CUs busy) is cut into quadrant tasks
             const int left = n_tiles % grid;
-            const int n_full = (left > 0 && left * 4 <= grid) ? n_tiles - left : n_tiles;
+            static const bool split_tail = !(std::getenv("MI_GEMM_SPLIT") && std::atoi(std::getenv("MI_GEMM_SPLIT")) == 0);  // A/B hook
+            const int n_full = (split_tail && left > 0 && left * 4 <= grid) ? n_tiles - left : n_tiles;
             static const int l2_order = std::getenv("MI_GEMM_ORDER") ? std::atoi(std::getenv("MI_GEMM_ORDER")) : 0;  // 1 = XCD-patch order (47.4 vs 46.1 ms in the tower: off)
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, (int)Mp, N,
                                K, ldo, n_tiles, n_full, l2_order);

@@ -1115,8 +1115,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
 #undef PP_STAGE
     }
 
-    // ---- the last, partial round as quadrant tasks (as in gemm_bf16_persist_kernel)
+    // ---- the last, partial round: tiles [n_full, n_tiles) are cut into four quadrant tasks each
+    // (64 rows per wave-row x 32 columns per wave-column = quadrant (mh, nh) of the tile), so that up to
+    // 4x more CUs share it.  A task only needs the X / W half-tiles of its quadrant: four LDS slots
+    // (the four half-tile positions of the two buffers) hold four K tiles, staged 3 ahead, ONE barrier
+    // per K tile: slot (kq+3)&3 is refilled behind the barrier of iteration kq, after every wave has
+    // retired its reads of it in iteration kq-1.
     const int n_tasks = (n_tiles - n_full) * 4;
+    auto stage_task = [&](int slot, uint32_t xs, uint32_t ws, int kt) {
+        unsigned char* dx = smem + (slot & 1) * 65536 + (slot >> 1) * 16384 + wave * 2048;
+        unsigned char* dw = dx + 32768;
+        const uint32_t sx = xs + x_wave + (uint32_t)kt * 128u, sw = ws + w_wave + (uint32_t)kt * 128u;
+        glds16_buf(xr, x_lane, sx, dx);
+        glds16_buf(xr, x_lane, sx + 8u * Kb, dx + 1024);
+        glds16_buf(wr, x_lane, sw, dw);
+        glds16_buf(wr, x_lane, sw + 8u * Kb, dw + 1024);
+    };
     for (int task = lb; task < n_tasks; task += G) {
         const int t = n_full + (task >> 2), mh = (task >> 1) & 1, nh = task & 1;
         const int ttm = t / nt, ttn = t - ttm * nt;
@@ -1124,17 +1138,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
         PP_BAR
         const uint32_t txs = (uint32_t)ttm * 256u * Kb + 64u * mh * Kb, tws = (uint32_t)ttn * 256u * Kb + 32u * nh * Kb;
         stage_bias(ttn);
-        stage_half(0, txs, tws, 0, 0); stage_half(0, txs, tws, 0, 1);
-        if (nk > 1) { stage_half(1, txs, tws, 1, 0); stage_half(1, txs, tws, 1, 1); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < nk) stage_task(k, txs, tws, k);
         for (int kq = 0; kq < nk; ++kq) {
-            if (kq + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            const int rem = nk - 1 - kq;  // K tiles issued behind this one and still allowed in flight: min(rem, 2)
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PP_BAR
+            if (kq + 3 < nk) stage_task((kq + 3) & 3, txs, tws, kq + 3);
             const unsigned char* base = smem + (kq & 1) * 65536;
-            load_x(base, 0); load_w(w0f, base, 0);
+            load_x(base, (kq >> 1) & 1); load_w(w0f, base, (kq >> 1) & 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            PP_BAR  // every wave has its fragments: the buffer may be refilled
-            if (kq + 2 < nk) { stage_half(kq & 1, txs, tws, kq + 2, 0); stage_half(kq & 1, txs, tws, kq + 2, 1); }
             PP_QUADRANT(0, 0, w0f)
         }
         __builtin_amdgcn_sched_barrier(0);
