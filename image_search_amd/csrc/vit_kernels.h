@@ -1254,6 +1254,24 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
     }
 }
 
+// max over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), VALU only: v_permlane16_swap /
+// v_permlane32_swap exchange rows between two copies of the value (swap16: rows 1<->0 and 3<->2 of
+// (a, b); swap32: rows 2,3 <-> 0,1), so max(a', b') holds max(own, partner) in every lane -- no LDS
+// crossbar round trip (ds_bpermute) on the softmax's critical path.
+__device__ __forceinline__ float xmax_rows(float v) {
+#ifdef ATTN_SHFL_MAX
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+#else
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned w = __float_as_uint(v);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+#endif
+}
+
 // ------------------------------------------------------------------ attention, bf16 MFMA
 // One workgroup per (image, head); K and V of the head ([S_PAD][64] bf16, 128-byte
 // rows, 16-byte chunks XOR-swizzled with row&7) stay in LDS; each wave walks query
@@ -1339,8 +1357,7 @@ __device__ __forceinline__ void attn_tiles(const unsigned char* __restrict__ Ks,
                 mx = fmaxf(mx, fmaxf(fmaxf(sc[u][T][0], sc[u][T][1]), fmaxf(sc[u][T][2], sc[u][T][3])));
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xmax_rows(mx);
         const float mc = -mx * C2;
 #pragma unroll
         for (int s = 0; s < NPV; ++s)
@@ -1470,8 +1487,7 @@ __device__ __forceinline__ void attn_pair(const unsigned char* __restrict__ Ks, 
                 mx = fmaxf(mx, fmaxf(fmaxf(sc[T][0], sc[T][1]), fmaxf(sc[T][2], sc[T][3])));
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xmax_rows(mx);
         return -mx * C2;
     };
     auto exp_pack4 = [&](const v4f& sc, float mc, bool live, bf16x8& dst, int half) {
