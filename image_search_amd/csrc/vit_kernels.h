@@ -40,7 +40,13 @@ enum { EPI_STORE_F32 = 0, EPI_BIAS = 1, EPI_BIAS_QGELU = 2, EPI_BIAS_RESID = 3 }
 
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
-__device__ __forceinline__ uint32_t pack2bf(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+// two floats -> one dword of bf16 (a in the low half): ONE v_cvt_pk_bf16_f32 (the element-wise form cost
+// two converts + and + or per pair in every epilogue)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((v2f){a, b}, bf16x2));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
