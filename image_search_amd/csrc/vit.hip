@@ -562,7 +562,7 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     for (int p = 0; p < parts; ++p) {
         Part& q = pt[p];
         // patch embedding: gather -> GEMM [P,Kp] x [D,Kp]^T -> f32
-        const size_t total = q.P * m->Kp;
+        const size_t total = q.P * 3 * (size_t)m->patch;  // one thread per patch-row segment
         const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65535 * 4);
         if (m->precision == MI_PRECISION_F32)
             hipLaunchKernelGGL((im2col_kernel<float>), dim3(blocks), dim3(256), 0, q.s, q.img, (float*)q.a->col, (int)q.n, m->grid, m->patch, m->image, m->Kp);

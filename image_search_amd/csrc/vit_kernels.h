@@ -90,20 +90,31 @@ __global__ void preprocess_rgb8_kernel(const uint8_t* __restrict__ rgb, float* _
 template <typename T>
 __global__ void im2col_kernel(const float* __restrict__ img, T* __restrict__ col, int n, int G, int P, int HW,
                               int Kp) {
-    const int PP = P * P, K = 3 * PP;
-    const size_t total = (size_t)n * G * G * Kp;
+    // one thread = one patch-row segment: P contiguous pixels of (image b, channel c, row gy*P+py) ->
+    // P contiguous columns k = c*P*P + py*P .. of col row (b, gy, gx).  Columns >= 3*P*P are never
+    // written: the workspace is zero-filled at allocation and stays so.
+    const size_t total = (size_t)n * G * G * 3 * P;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(idx % Kp);
-        const size_t row = idx / Kp;
-        float v = 0.0f;
-        if (k < K) {
-            const int c = k / PP, rem = k % PP, py = rem / P, px = rem % P;
-            const int gx = (int)(row % G), gy = (int)((row / G) % G);
-            const size_t b = row / ((size_t)G * G);
-            v = img[((b * 3 + c) * HW + (size_t)(gy * P + py)) * HW + gx * P + px];
+        const int gx = (int)(idx % G);  // fastest: neighbouring threads read neighbouring 4P-byte runs of one image row
+        size_t r = idx / G;
+        const int py = (int)(r % P); r /= P;
+        const int c = (int)(r % 3); r /= 3;
+        const int gy = (int)(r % G);
+        const size_t b = r / G;
+        const float* src = img + ((b * 3 + c) * HW + (size_t)(gy * P + py)) * HW + (size_t)gx * P;
+        T* dst = col + ((b * G + gy) * G + gx) * (size_t)Kp + (size_t)(c * P + py) * P;
+        if ((P & 1) == 0) {
+            for (int px = 0; px < P; px += 2) {
+                const v2f v = *reinterpret_cast<const v2f*>(src + px);
+                if constexpr (sizeof(T) == 4) { dst[px] = v.x; dst[px + 1] = v.y; }
+                else *reinterpret_cast<uint32_t*>(dst + px) = pack2bf(v.x, v.y);
+            }
+        } else {
+            for (int px = 0; px < P; ++px) {
+                if constexpr (sizeof(T) == 4) dst[px] = src[px]; else dst[px] = f2bf(src[px]);
+            }
         }
-        if constexpr (sizeof(T) == 4) col[idx] = v; else col[idx] = f2bf(v);
     }
 }
 
