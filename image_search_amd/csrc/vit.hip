@@ -193,7 +193,7 @@ struct mi_clip {
     // workspace for `cap` images
     size_t cap = 0;
     std::vector<void*> ws;
-    float *d_in = nullptr, *d_out = nullptr;
+    float *d_in = nullptr, *d_in2 = nullptr, *d_out = nullptr, *d_out2 = nullptr;
     // activations: set 0 serves a whole chunk; set 1 exists so that two half-chunks can run as two
     // independent streams (see forward()).
     struct Act {
@@ -390,6 +390,7 @@ void ensure_workspace(mi_clip* m, size_t n) {
     };
     const size_t px = (size_t)m->image * m->image * 3;
     m->d_in = (float*)bytes(n * px * 4);
+    m->d_in2 = (float*)bytes(n * px * 4);  // mi_clip_embed: upload of chunk i+1 under the forward of chunk i
     m->d_rgb = (uint8_t*)bytes(n * px);
     for (int a = 0; a < 4; ++a) {
         const size_t na = a == 0 ? n : (n + 1) / 2;
@@ -406,6 +407,7 @@ void ensure_workspace(mi_clip* m, size_t n) {
     }
     (void)Mp; (void)Pp;
     m->d_out = (float*)bytes(n * m->E * 4);
+    m->d_out2 = (float*)bytes(n * m->E * 4);
     HIP_CHECK(hipStreamSynchronize(m->stream));
     m->cap = n;
 }
@@ -613,6 +615,15 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     }
 }
 
+void ensure_copy_stream(mi_clip* m) {
+    if (m->copy_stream) return;
+    HIP_CHECK(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        HIP_CHECK(hipEventCreateWithFlags(&m->ev_up[b], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&m->ev_used[b], hipEventDisableTiming));
+    }
+}
+
 // ---- text tower: workspace and forward (fp32) -------------------------------------------
 void ensure_text_workspace(mi_clip* m, size_t n) {
     if (n <= m->text_cap) return;
@@ -798,13 +809,30 @@ int mi_clip_embed(mi_clip* m, const float* nchw, size_t n, float* out) {
         const size_t px = (size_t)m->image * m->image * 3;
         const size_t chunk = std::min(n, m->max_batch);
         ensure_workspace(m, chunk);
-        for (size_t i = 0; i < n; i += chunk) {
-            const size_t c = std::min(chunk, n - i);
-            HIP_CHECK(hipMemcpyAsync(m->d_in, nchw + i * px, c * px * 4, hipMemcpyHostToDevice, m->stream));
-            forward(m, m->d_in, c, m->d_out, m->stream);
-            HIP_CHECK(hipMemcpyAsync(out + i * m->E, m->d_out, c * m->E * 4, hipMemcpyDeviceToHost, m->stream));
-            HIP_CHECK(hipStreamSynchronize(m->stream));
+        ensure_copy_stream(m);
+        // two input / output buffers: the upload of chunk i+1 (copy stream) runs under the forward of
+        // chunk i, the readback of chunk i under the forward of chunk i+1
+        float* din[2] = {m->d_in, m->d_in2};
+        float* dout[2] = {m->d_out, m->d_out2};
+        const size_t nchunks = (n + chunk - 1) / chunk;
+        auto upload = [&](size_t ci) {
+            const size_t i = ci * chunk, c = std::min(chunk, n - i);
+            const int b = (int)(ci & 1);
+            if (ci >= 2) HIP_CHECK(hipStreamWaitEvent(m->copy_stream, m->ev_used[b], 0));  // forward(ci-2) consumed it
+            HIP_CHECK(hipMemcpyAsync(din[b], nchw + i * px, c * px * 4, hipMemcpyHostToDevice, m->copy_stream));
+            HIP_CHECK(hipEventRecord(m->ev_up[b], m->copy_stream));
+        };
+        upload(0);
+        for (size_t ci = 0; ci < nchunks; ++ci) {
+            const size_t i = ci * chunk, c = std::min(chunk, n - i);
+            const int b = (int)(ci & 1);
+            HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_up[b], 0));
+            forward(m, din[b], c, dout[b], m->stream);
+            HIP_CHECK(hipEventRecord(m->ev_used[b], m->stream));
+            if (ci + 1 < nchunks) upload(ci + 1);  // pageable source: blocks this thread while the GPU computes
+            HIP_CHECK(hipMemcpyAsync(out + i * m->E, dout[b], c * m->E * 4, hipMemcpyDeviceToHost, m->stream));
         }
+        HIP_CHECK(hipStreamSynchronize(m->stream));
     });
 }
 
@@ -869,13 +897,7 @@ int mi_clip_embed_images(mi_clip* m, const uint8_t* const* rgb8, const uint32_t*
             HIP_CHECK(hipMalloc((void**)&m->d_img_tmp, max_tmp));
             m->img_tmp_cap = max_tmp;
         }
-        if (!m->copy_stream) {
-            HIP_CHECK(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
-            for (int b = 0; b < 2; ++b) {
-                HIP_CHECK(hipEventCreateWithFlags(&m->ev_up[b], hipEventDisableTiming));
-                HIP_CHECK(hipEventCreateWithFlags(&m->ev_used[b], hipEventDisableTiming));
-            }
-        }
+        ensure_copy_stream(m);
         for (size_t i0 = 0; i0 < n; i0 += chunk) {
             const size_t c = std::min(chunk, n - i0);
             for (size_t j = 0; j < c; ++j) {
