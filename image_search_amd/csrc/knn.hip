@@ -446,15 +446,26 @@ int mi_knn_search(mi_knn* t, const float* q, uint32_t nq, uint32_t k, uint64_t* 
         std::lock_guard<std::mutex> l(t->mu);
         DeviceGuard g(t->device);
         own_stream(t);
-        ensure((void**)&t->d_idx, &t->idx_cap, k, sizeof(uint64_t));
-        ensure((void**)&t->d_dist, &t->dist_cap, k, sizeof(float));
-        for (uint32_t u = 0; u < nq; ++u) {
-            HIP_CHECK(hipMemcpyAsync(t->d_q, q + (size_t)u * t->dim, t->dim * sizeof(float), hipMemcpyHostToDevice,
+        // groups of up to 16 queries: one upload, table passes of 8 / 4 / 2 queries where the register
+        // path applies (k <= 64; same arithmetic per query as the single-query pass), one readback
+        constexpr uint32_t GROUP = 16;
+        ensure((void**)&t->d_idx, &t->idx_cap, (size_t)GROUP * k, sizeof(uint64_t));
+        ensure((void**)&t->d_dist, &t->dist_cap, (size_t)GROUP * k, sizeof(float));
+        for (uint32_t u0 = 0; u0 < nq; u0 += GROUP) {
+            const uint32_t ng = std::min(GROUP, nq - u0);
+            HIP_CHECK(hipMemcpyAsync(t->d_q, q + (size_t)u0 * t->dim, (size_t)ng * t->dim * sizeof(float),
+                                     hipMemcpyHostToDevice, t->stream));
+            uint32_t u = 0;
+            while (u < ng) {
+                const uint32_t left = ng - u;
+                const uint32_t b = (k <= 64 && t->rows && t->dim == 768) ? (left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1) : 1;
+                if (b == 1) search_one(t, t->d_q + (size_t)u * t->dim, k, t->d_idx + (size_t)u * k, t->d_dist + (size_t)u * k, t->stream);
+                else search_batched(t, t->d_q + (size_t)u * t->dim, b, k, t->d_idx + (size_t)u * k, t->d_dist + (size_t)u * k, t->stream);
+                u += b;
+            }
+            HIP_CHECK(hipMemcpyAsync(idx + (size_t)u0 * k, t->d_idx, (size_t)ng * k * sizeof(uint64_t), hipMemcpyDeviceToHost,
                                      t->stream));
-            search_one(t, t->d_q, k, t->d_idx, t->d_dist, t->stream);
-            HIP_CHECK(hipMemcpyAsync(idx + (size_t)u * k, t->d_idx, k * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                                     t->stream));
-            HIP_CHECK(hipMemcpyAsync(dist + (size_t)u * k, t->d_dist, k * sizeof(float), hipMemcpyDeviceToHost,
+            HIP_CHECK(hipMemcpyAsync(dist + (size_t)u0 * k, t->d_dist, (size_t)ng * k * sizeof(float), hipMemcpyDeviceToHost,
                                      t->stream));
             HIP_CHECK(hipStreamSynchronize(t->stream));
         }
