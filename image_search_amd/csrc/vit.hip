@@ -200,6 +200,10 @@ struct mi_clip {
         float *patch = nullptr, *x = nullptr;
         void *col = nullptr, *y = nullptr, *qkv = nullptr, *h = nullptr;
         bf16_t *delta = nullptr, *delta2 = nullptr;  // bf16 path: out_proj / fc2 outputs, added to x by LayerNorm
+        // last layer, CLS rows only (n rows, padded to 256): context, residual, LN output, MLP hidden, deltas
+        void *c_ctx = nullptr, *c_y = nullptr, *c_h = nullptr;
+        float* c_x = nullptr;
+        bf16_t *c_d1 = nullptr, *c_d2 = nullptr;
     } act[4];
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -404,6 +408,13 @@ void ensure_workspace(mi_clip* m, size_t n) {
         m->act[a].h = bytes(Ma * m->FF * es);
         m->act[a].delta = (bf16_t*)bytes(Ma * m->D * 2);
         m->act[a].delta2 = (bf16_t*)bytes(Ma * m->D * 2);
+        const size_t Ca = pad256(na);
+        m->act[a].c_ctx = bytes(Ca * m->D * es);
+        m->act[a].c_y = bytes(Ca * m->D * es);
+        m->act[a].c_h = bytes(Ca * m->FF * es);
+        m->act[a].c_x = (float*)bytes(Ca * m->D * 4);
+        m->act[a].c_d1 = (bf16_t*)bytes(Ca * m->D * 2);
+        m->act[a].c_d2 = (bf16_t*)bytes(Ca * m->D * 2);
     }
     (void)Mp; (void)Pp;
     m->d_out = (float*)bytes(n * m->E * 4);
@@ -509,10 +520,12 @@ void layer_norm(mi_clip* m, float* x, const bf16_t* d1, const bf16_t* d2, bool w
     HIP_CHECK(hipGetLastError());
 }
 
-void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s) {
+// first_tile_only: only the leading query tile / block of every (image, head) -- it holds the CLS row
+void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, bool first_tile_only = false) {
     if (m->precision == MI_PRECISION_F32) {
-        const unsigned blocks = (unsigned)(n * m->H * ((m->S + 63) / 64));
-        hipLaunchKernelGGL(attn_f32_kernel, dim3(blocks), dim3(64), 0, s, (const float*)qkv, (float*)ctx, m->S, m->D, m->H, m->text ? 1 : 0);
+        const int qb = first_tile_only ? 1 : (m->S + 63) / 64;
+        const unsigned blocks = (unsigned)(n * m->H * qb);
+        hipLaunchKernelGGL(attn_f32_kernel, dim3(blocks), dim3(64), 0, s, (const float*)qkv, (float*)ctx, m->S, m->D, m->H, m->text ? 1 : 0, first_tile_only ? 1 : 0);
     } else {
         const unsigned blocks = (unsigned)(n * m->H);
         const int sp = (m->S + 31) / 32 * 32;
@@ -520,7 +533,7 @@ void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s) 
     {                                                                                                                \
         static bool done = false;                                                                                    \
         if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)attn_bf16_kernel<SP, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, SP * 256)); done = true; } \
-        hipLaunchKernelGGL((attn_bf16_kernel<SP, SC>), dim3(blocks), dim3(256), SP * 256, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H); \
+        hipLaunchKernelGGL((attn_bf16_kernel<SP, SC>), dim3(blocks), dim3(256), SP * 256, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, first_tile_only ? 1 : 0); \
     }
         if (m->S == 257) MI_ATTN(288, 257)       // ViT-L/14, ViT-H/14 @224
         else if (m->S == 197) MI_ATTN(224, 197)  // ViT-B/16 @224
@@ -580,12 +593,44 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     // bf16 path: out_proj / fc2 store bf16 `delta` / `delta2` (pure, asynchronous stores from the
     // persistent GEMM).  LN2 normalises x + delta without writing x; the next LN1 forms
     // (x + delta) + delta2 — the same order — writes it back and normalises it.
-    for (const Layer& ly : m->layers) {
+    // The pooled output is the CLS row (modeling_clip.py:641-651), so behind the LAST layer's attention
+    // only that row of every image is live: its context row is gathered and out_proj, LN2, the MLP and
+    // the head run on n rows instead of n*S (same arithmetic per row, so the same bits; the reference's
+    // graph computes the other rows and discards them).  MI_CLIP_FULL_LAST=1 keeps the full last layer.
+    const char* fl = std::getenv("MI_CLIP_FULL_LAST");  // read per call: the parity test toggles it
+    const bool full_last = fl && std::atoi(fl) != 0;
+    for (size_t li = 0; li < m->layers.size(); ++li) {
+        const Layer& ly = m->layers[li];
+        const bool last = !full_last && li + 1 == m->layers.size();
         for (int p = 0; p < parts; ++p) {
             Part& q = pt[p];
             layer_norm(m, q.a->x, q.p1, q.p2, true, q.a->y, ly.ln1w, ly.ln1b, q.M, q.s);
             gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, D, 3 * D, q.s);
-            attention(m, q.a->qkv, q.a->y, q.n, q.s);
+            attention(m, q.a->qkv, q.a->y, q.n, q.s, last);
+        }
+        if (last) {
+            for (int p = 0; p < parts; ++p) {
+                Part& q = pt[p];
+                const unsigned gb = (unsigned)std::min<size_t>((q.n * (size_t)D / 4 + 255) / 256, 4096);
+                if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, q.s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_ctx, (int)q.n, (size_t)S, D);
+                else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb), dim3(256), 0, q.s, (const float*)q.a->y, (float*)q.a->c_ctx, (int)q.n, (size_t)S, D);
+                hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb), dim3(256), 0, q.s, (const float*)q.a->x, q.a->c_x, (int)q.n, (size_t)S, D);
+                HIP_CHECK(hipGetLastError());
+                if (deferred) {
+                    gemm<EPI_BIAS>(m, q.a->c_ctx, ly.wo, ly.bo, q.a->c_d1, q.n, D, D, D, q.s);
+                    layer_norm(m, q.a->c_x, q.a->c_d1, nullptr, false, q.a->c_y, ly.ln2w, ly.ln2b, q.n, q.s);
+                    gemm<EPI_BIAS_QGELU>(m, q.a->c_y, ly.w1, ly.b1, q.a->c_h, q.n, FF, D, FF, q.s);
+                    gemm<EPI_BIAS>(m, q.a->c_h, ly.w2, ly.b2, q.a->c_d2, q.n, D, FF, D, q.s);
+                } else {
+                    gemm<EPI_BIAS_RESID>(m, q.a->c_ctx, ly.wo, ly.bo, q.a->c_x, q.n, D, D, D, q.s);
+                    layer_norm(m, q.a->c_x, nullptr, nullptr, true, q.a->c_y, ly.ln2w, ly.ln2b, q.n, q.s);
+                    gemm<EPI_BIAS_QGELU>(m, q.a->c_y, ly.w1, ly.b1, q.a->c_h, q.n, FF, D, FF, q.s);
+                    gemm<EPI_BIAS_RESID>(m, q.a->c_h, ly.w2, ly.b2, q.a->c_x, q.n, D, FF, D, q.s);
+                }
+                MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, q.s, q.a->c_x, deferred ? q.a->c_d1 : (const bf16_t*)nullptr, deferred ? q.a->c_d2 : (const bf16_t*)nullptr, m->post_w, m->post_b, m->proj, q.out, (int)q.n, 1, m->E, m->eps, (const int*)nullptr));
+                HIP_CHECK(hipGetLastError());
+            }
+            break;
         }
         for (int p = 0; p < parts; ++p) {
             Part& q = pt[p];
@@ -603,7 +648,7 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
             }
         }
     }
-    for (int p = 0; p < parts; ++p) {
+    for (int p = 0; p < parts && full_last; ++p) {
         Part& q = pt[p];
         // fp32 in both precisions: the embedding that goes to the table is not rounded to bf16 anywhere here
         MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, q.s, q.a->x, q.p1, q.p2, m->post_w, m->post_b, m->proj, q.out, (int)q.n, S, m->E, m->eps, (const int*)nullptr));

@@ -251,6 +251,17 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
     r.store(x + (size_t)row * D, lane);
 }
 
+// ------------------------------------------------------------------ row gather (last layer: CLS rows only)
+// dst[i][:] = src[i * stride_rows][:], rows of D elements of T (16-byte pieces)
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, size_t stride_rows, int D) {
+    const int per = D * (int)sizeof(T) / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n * per; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / per, c = i % per;
+        reinterpret_cast<v4u*>(dst + r * D)[c] = reinterpret_cast<const v4u*>(src + r * stride_rows * D)[c];
+    }
+}
+
 // ------------------------------------------------------------------ text tower front / pooling index
 // x[r][:] = token_embedding[ids[r]] + position_embedding[r % S]   (CLIPTextEmbeddings.forward)
 __global__ void text_embed_kernel(const int* __restrict__ ids, const float* __restrict__ tok,
@@ -1207,12 +1218,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
 // softmax(q k^T / 8) v per (image, head), one thread per query row, keys streamed
 // through LDS in chunks of 64, running max / sum (modeling_clip.py:259-277).
 // causal != 0: key j is visible to query i iff j <= i (the text tower's mask).
+// q_blocks > 0: only the first q_blocks blocks of 64 queries of every (image, head) are computed (the
+// last layer needs the CLS row only).
 __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int S,
-                                                      int D, int H, int causal) {
+                                                      int D, int H, int causal, int q_blocks) {
     __shared__ __attribute__((aligned(16))) float Ks[64][64];
     __shared__ __attribute__((aligned(16))) float Vs[64][64];
     const int tid = threadIdx.x;
-    const int nqt = (S + 63) / 64;
+    const int nqt = q_blocks > 0 ? q_blocks : (S + 63) / 64;
     const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt;
     const int b = bh / H, hh = bh % H;
     const size_t ld = (size_t)3 * D;
@@ -1642,7 +1655,7 @@ __device__ __forceinline__ void attn_pair(const unsigned char* __restrict__ Ks, 
 
 template <int S_PAD, int S_CT>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bf16_kernel(
-    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int S_rt, int D, int H) {
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int S_rt, int D, int H, int q_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ks = smem;
     unsigned char* Vs = smem + S_PAD * 128;
@@ -1676,7 +1689,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
     // query tiles of this wave: w', w'+4, ... with the start rotated between co-resident workgroups;
     // they are taken two at a time, a last odd one alone
-    const int nqt = (S + 15) / 16;
+    // q_tiles > 0: only that many leading query tiles (the last layer needs the CLS row = row 0 only)
+    const int nqt = q_tiles > 0 ? min(q_tiles, (S + 15) / 16) : (S + 15) / 16;
     bf16_t* ctx_b = ctx + (size_t)b * S * D + hh * 64;
     int q0 = (wave + blockIdx.x) & 3;
     for (; q0 + 4 < nqt; q0 += 8) {

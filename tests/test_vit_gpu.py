@@ -286,3 +286,16 @@ def test_persistent_gemm_random_shapes_and_grids(built, monkeypatch):
         assert np.abs(ref).max() <= 256
         got = ops.linear(x, w, b, ops.EPI_BIAS, PRECISION_BF16)
         assert np.array_equal(got, ref), (case, grid, m, n, k)
+
+
+@pytest.mark.parametrize("prec", [PRECISION_F32, PRECISION_BF16])
+def test_cls_only_last_layer_is_bit_identical_to_the_full_one(l14, monkeypatch, prec):
+    """Behind the last layer's attention only the CLS row is live; computing just that row must give
+    the very bits of the full last layer (same per-row arithmetic), for one and for two half-chunks."""
+    cfg, w, path, u8, g = l14
+    px = synth.preprocess_rgb8(synth.images_u8(77, 40, cfg.image))      # 40 images: two half-chunk streams in bf16
+    m = Model.from_file(path, 0, prec)
+    fast = m.forward(px)
+    monkeypatch.setenv("MI_CLIP_FULL_LAST", "1")
+    full = m.forward(px)
+    assert np.array_equal(fast.view(np.uint32), full.view(np.uint32))

@@ -21,10 +21,10 @@ int main() {
     auto kern = attn_bf16_kernel<288, 257>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 288 * 256));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kern, dim3(n * H), dim3(256), 288 * 256, 0, qkv, ctx, S, D, H);
+    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kern, dim3(n * H), dim3(256), 288 * 256, 0, qkv, ctx, S, D, H, 0);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int it = 0; it < 20; ++it) hipLaunchKernelGGL(kern, dim3(n * H), dim3(256), 288 * 256, 0, qkv, ctx, S, D, H);
+    for (int it = 0; it < 20; ++it) hipLaunchKernelGGL(kern, dim3(n * H), dim3(256), 288 * 256, 0, qkv, ctx, S, D, H, 0);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("ABL=%d: %.1f us per launch\n", ABL, ms / 20 * 1000);
