@@ -605,7 +605,21 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
         for (int p = 0; p < parts; ++p) {
             Part& q = pt[p];
             layer_norm(m, q.a->x, q.p1, q.p2, true, q.a->y, ly.ln1w, ly.ln1b, q.M, q.s);
-            gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, D, 3 * D, q.s);
+            if (!last) {
+                gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, D, 3 * D, q.s);
+            } else {
+                // keys and values of every token, queries of the CLS rows only (the other rows of the
+                // leading query tile keep whatever the buffer held: their context rows are never read)
+                const size_t es = esize(m);
+                gemm<EPI_BIAS>(m, q.a->y, (const char*)ly.wqkv + (size_t)D * D * es, ly.bqkv + D, (char*)q.a->qkv + (size_t)D * es, q.M, 2 * D, D, 3 * D, q.s);
+                const unsigned gb = (unsigned)std::min<size_t>((q.n * (size_t)D / 4 + 255) / 256, 4096);
+                if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, q.s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_y, (int)q.n, (size_t)S, D);
+                else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb), dim3(256), 0, q.s, (const float*)q.a->y, (float*)q.a->c_y, (int)q.n, (size_t)S, D);
+                gemm<EPI_BIAS>(m, q.a->c_y, ly.wqkv, ly.bqkv, q.a->c_ctx, q.n, D, D, D, q.s);
+                if (deferred) hipLaunchKernelGGL((scatter_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, q.s, (const bf16_t*)q.a->c_ctx, (bf16_t*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)3 * D);
+                else hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3(gb), dim3(256), 0, q.s, (const float*)q.a->c_ctx, (float*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)3 * D);
+                HIP_CHECK(hipGetLastError());
+            }
             attention(m, q.a->qkv, q.a->y, q.n, q.s, last);
         }
         if (last) {

@@ -262,6 +262,16 @@ __global__ void gather_rows_kernel(const T* __restrict__ src, T* __restrict__ ds
     }
 }
 
+// dst[i * stride_rows][0 .. D) = src[i][0 .. D) with dst row pitch ld elements (the CLS queries of the last layer)
+template <typename T>
+__global__ void scatter_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, size_t stride_rows, int D, size_t ld) {
+    const int per = D * (int)sizeof(T) / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n * per; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / per, c = i % per;
+        reinterpret_cast<v4u*>(dst + r * stride_rows * ld)[c] = reinterpret_cast<const v4u*>(src + r * D)[c];
+    }
+}
+
 // ------------------------------------------------------------------ text tower front / pooling index
 // x[r][:] = token_embedding[ids[r]] + position_embedding[r % S]   (CLIPTextEmbeddings.forward)
 __global__ void text_embed_kernel(const int* __restrict__ ids, const float* __restrict__ tok,
