@@ -23,6 +23,7 @@ SYMBOLS = {
     "mi_device_count": (ctypes.c_int, []),
     "mi_clip_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "mi_clip_free": (None, [c_vp]),
+    "mi_clip_set_option": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
     "mi_clip_info": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "mi_clip_embed": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "mi_clip_embed_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp]),
@@ -50,6 +51,15 @@ SYMBOLS = {
     "mi_knn_search_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp]),
     "mi_knn_search_batched_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp]),
     "mi_knn_merge": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
+    "mi_pipeline_create": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
+    "mi_pipeline_free": (None, [c_vp]),
+    "mi_pipeline_ingest": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_u64p]),
+    "mi_pipeline_query": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, c_vp, c_vp]),
+    "mi_pipeline_sync": (ctypes.c_int, [c_vp]),
+    "mi_pipeline_drain": (ctypes.c_int, [c_vp, ctypes.c_uint32]),
+    "mi_pipeline_stats": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
+    "mi_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(c_vp)]),
+    "mi_host_free": (None, [c_vp]),
     "mi_average_slices": (ctypes.c_int, [ctypes.POINTER(c_f), ctypes.c_size_t, ctypes.c_size_t, c_f]),
     "mi_refine": (ctypes.c_int, [c_f, ctypes.POINTER(c_f), ctypes.c_size_t, ctypes.c_size_t, c_f]),
     # include/mi355clip_ops.h (per-op test hooks)

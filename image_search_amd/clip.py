@@ -115,6 +115,10 @@ class Model:
     def forward_device(self, d_nchw: int, n: int, d_out: int, stream: int = 0):
         check(lib().mi_clip_embed_device(self._h, d_nchw, n, d_out, stream))
 
+    def set_option(self, key: str, value: int):
+        """max_batch / parts / full_last / split_tail (include/mi355clip.h: mi_clip_set_option)."""
+        check(lib().mi_clip_set_option(self._h, key.encode(), int(value)))
+
 
 class TextModel:
     """The CLIP text tower on one MI355X: what `clip(state, text)` obtains from embed_anything

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -68,6 +69,48 @@ struct DeviceGuard {
     }
     ~DeviceGuard() {
         if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per (device, function): one DevOnce per call site
+// remembers which devices already have it (a second handle on another GPU of the same process, or two
+// threads loading handles at once, must not skip it; setting it twice is harmless).
+struct DevOnce {
+    std::atomic<uint64_t> mask{0};
+};
+template <class K>
+inline void allow_lds_once(DevOnce& once, K kernel, int bytes) {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (once.mask.load(std::memory_order_acquire) & bit) return;
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    once.mask.fetch_or(bit, std::memory_order_release);
+}
+
+// Order of the work of ONE handle across streams.  Every entry point that enqueues work which touches
+// the handle's buffers calls begin(s) first (s waits for whatever the handle enqueued last, on any
+// stream) and end(s) last.  Work on a handle therefore runs in call order whichever streams the
+// callers pass; the host never blocks.  sync() is for the few places that free or move buffers.
+struct WorkOrder {
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    void begin(hipStream_t s) {
+        if (pending) HIP_CHECK(hipStreamWaitEvent(s, ev, 0));
+    }
+    void end(hipStream_t s) {
+        if (!ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev, s));
+        pending = true;
+    }
+    void sync() {
+        if (pending) HIP_CHECK(hipEventSynchronize(ev));
+        pending = false;
+    }
+    void destroy() {
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;
+        pending = false;
     }
 };
 

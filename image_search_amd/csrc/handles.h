@@ -1,0 +1,107 @@
+// handles.h — the opaque handles of include/mi355clip.h as the library's translation units see them,
+// plus the few host-side routines that cross files (the fused pipeline and the sharded table are built
+// from the same forward / scan launchers as the single-handle entry points).
+#pragma once
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace mi {
+typedef unsigned short bf16_t;
+
+struct Layer {
+    float *ln1w, *ln1b, *ln2w, *ln2b;
+    void *wqkv, *wo, *w1, *w2;  // T [N][K]
+    float *bqkv, *bo, *b1, *b2;
+};
+
+
+}  // namespace mi
+
+struct mi_clip {
+    int device = 0, precision = 0;
+    int image = 0, patch = 0, grid = 0, S = 0, D = 0, L = 0, H = 0, FF = 0, E = 0, Kp = 0;
+    float eps = 1e-5f;
+    std::vector<void*> allocs;
+    float *cls = nullptr, *pos = nullptr, *pre_w = nullptr, *pre_b = nullptr, *post_w = nullptr, *post_b = nullptr,
+          *proj = nullptr;
+    void* wpatch = nullptr;  // T [D][Kp]
+    std::vector<mi::Layer> layers;
+    // workspace for `cap` images
+    size_t cap = 0;
+    std::vector<void*> ws;
+    float *d_in = nullptr, *d_in2 = nullptr, *d_out = nullptr, *d_out2 = nullptr;
+    // activations: set 0 serves a whole chunk; set 1 exists so that two half-chunks can run as two
+    // independent streams (see forward()).
+    struct Act {
+        float *patch = nullptr, *x = nullptr;
+        void *col = nullptr, *y = nullptr, *qkv = nullptr, *h = nullptr;
+        mi::bf16_t *delta = nullptr, *delta2 = nullptr;  // bf16 path: out_proj / fc2 outputs, added to x by LayerNorm
+        // last layer, CLS rows only (n rows, padded to 256): context, residual, LN output, MLP hidden, deltas
+        void *c_ctx = nullptr, *c_y = nullptr, *c_h = nullptr;
+        float* c_x = nullptr;
+        mi::bf16_t *c_d1 = nullptr, *c_d2 = nullptr;
+    } act[4];
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    int parts = 2;  // MI_CLIP_PARTS: sub-chunks run as independent streams
+    int n_cu = 256;
+    uint8_t* d_rgb = nullptr;
+    // text tower (mi_clip_load_text): token table, device copies of the ids and of the EOS rows
+    bool text = false;
+    int vocab = 0;
+    float* tok = nullptr;
+    int *d_ids = nullptr, *d_rows = nullptr;
+    size_t text_cap = 0;
+    // mi_clip_embed_images: two upload buffers for decoded images, the resize intermediate, a copy stream
+    uint8_t* d_img_src[2] = {nullptr, nullptr};
+    float* d_img_tmp = nullptr;
+    size_t img_src_cap = 0, img_tmp_cap = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    size_t max_batch = 256;
+    // options (mi_clip_set_option; the MI_CLIP_* / MI_GEMM_* environment variables only seed them at load)
+    bool full_last = false;   // compute the dead rows of the last layer too (A/B against the reference graph)
+    bool split_tail = true;   // cut a short last round of GEMM tiles into quadrant tasks
+    mi::WorkOrder order;          // serialises this handle's enqueued work across caller streams
+    std::mutex mu;
+};
+
+
+struct mi_knn {
+    int device = 0;
+    uint32_t dim = 0;
+    uint64_t base = 0, rows = 0, cap = 0;
+    float* table = nullptr;
+    hipStream_t stream = nullptr;
+    int n_cu = 0;
+    // search workspace
+    float* d_q = nullptr;        // [16][dim]
+    uint64_t* d_cand = nullptr;  // per-wave lists
+    uint64_t* d_tmp = nullptr;   // merge level output
+    uint64_t* d_keys = nullptr;  // final keys (k rounded up to 1024 multiples)
+    uint64_t* d_idx = nullptr;
+    float* d_dist = nullptr;
+    size_t cand_keys = 0, tmp_keys = 0, keys_cap = 0, idx_cap = 0, dist_cap = 0;
+    // Order across caller streams.  `writes`: the last append (a search must see every row counted in
+    // `rows`).  `reads`: the last search (searches share the workspace above, and a reallocation of the
+    // table must wait for them).  An append only ever writes rows beyond `rows`, so it does not wait
+    // for searches in flight: ingest and query streams overlap.
+    mi::WorkOrder writes, reads;
+    std::mutex mu;
+};
+
+
+namespace mi {
+// vit.hip
+hipStream_t clip_own_stream(mi_clip* m);
+void clip_ensure_workspace(mi_clip* m, size_t n);   // frees and reallocates: waits for the handle's pending work
+void clip_ensure_copy_stream(mi_clip* m);
+void clip_forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t s);
+// knn.hip
+hipStream_t knn_own_stream(mi_knn* t);
+void knn_grow(mi_knn* t, uint64_t want_rows);       // may reallocate: waits for the handle's pending work
+void knn_search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s);
+}  // namespace mi

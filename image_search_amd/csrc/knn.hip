@@ -9,34 +9,18 @@
 #include <vector>
 
 #include "common.h"
+#include "handles.h"
 #include "knn_kernels.h"
 
 using namespace mi;
-
-struct mi_knn {
-    int device = 0;
-    uint32_t dim = 0;
-    uint64_t base = 0, rows = 0, cap = 0;
-    float* table = nullptr;
-    hipStream_t stream = nullptr;
-    int n_cu = 0;
-    // search workspace
-    float* d_q = nullptr;        // [16][dim]
-    uint64_t* d_cand = nullptr;  // per-wave lists
-    uint64_t* d_tmp = nullptr;   // merge level output
-    uint64_t* d_keys = nullptr;  // final keys (k rounded up to 1024 multiples)
-    uint64_t* d_idx = nullptr;
-    float* d_dist = nullptr;
-    size_t cand_keys = 0, tmp_keys = 0, keys_cap = 0, idx_cap = 0, dist_cap = 0;
-    std::mutex mu;
-};
 
 namespace {
 
 constexpr int MAX_BATCH_Q = 8;
 
-void ensure(void** p, size_t* have, size_t want, size_t elem) {
+void ensure(mi_knn* t, void** p, size_t* have, size_t want, size_t elem) {
     if (*have >= want) return;
+    t->reads.sync();  // a search still in flight uses the buffer freed here
     if (*p) HIP_CHECK(hipFree(*p));
     *p = nullptr; *have = 0;
     HIP_CHECK(hipMalloc(p, want * elem));
@@ -56,6 +40,9 @@ void grow(mi_knn* t, uint64_t want_rows) {
     ncap = (ncap + 63) & ~63ull;
     if (ncap > 0xFFFFFFFFull) fail(MI_ERR_UNSUPPORTED, "a shard holds at most 2^32-1 rows (asked %llu)",
                                     (unsigned long long)want_rows);
+    // the table moves: everything enqueued against the old allocation must have finished
+    t->writes.sync();
+    t->reads.sync();
     float* nt = nullptr;
     HIP_CHECK(hipMalloc((void**)&nt, ncap * t->dim * sizeof(float)));
     if (t->rows) {
@@ -111,12 +98,12 @@ void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint
     uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * bpc, (n_tiles + 3) / 4);
     blocks = std::max(blocks, 1u);
     const uint32_t lists = blocks * 4;
-    ensure((void**)&t->d_cand, &t->cand_keys, (size_t)lists * kp, sizeof(uint64_t));
+    ensure(t, (void**)&t->d_cand, &t->cand_keys, (size_t)lists * kp, sizeof(uint64_t));
     launch_scan<Top>(t, d_q, kp, lo, t->d_cand, blocks, s);
     if constexpr (Top::LDS_KEYS != 0) {
         // k > 64: block-cooperative tree, 16 lists per block per level, ping-pong between d_tmp halves
         constexpr uint32_t LPB = 16;
-        ensure((void**)&t->d_tmp, &t->tmp_keys, (size_t)2 * ((lists + LPB - 1) / LPB) * kp, sizeof(uint64_t));
+        ensure(t, (void**)&t->d_tmp, &t->tmp_keys, (size_t)2 * ((lists + LPB - 1) / LPB) * kp, sizeof(uint64_t));
         const uint64_t* in = t->d_cand;
         uint32_t n = lists, lvl = 0;
         while (true) {
@@ -134,7 +121,7 @@ void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint
         launch_merge<Top>(t->d_cand, lists, kp, lists, keys_out, 1, 0, 0, s);
     } else {
         const uint32_t lpb = 32, mid = (lists + lpb - 1) / lpb;
-        ensure((void**)&t->d_tmp, &t->tmp_keys, (size_t)mid * kp, sizeof(uint64_t));
+        ensure(t, (void**)&t->d_tmp, &t->tmp_keys, (size_t)mid * kp, sizeof(uint64_t));
         launch_merge<Top>(t->d_cand, lists, kp, lpb, t->d_tmp, 1, 0, 0, s);
         launch_merge<Top>(t->d_tmp, mid, kp, mid, keys_out, 1, 0, 0, s);
     }
@@ -148,7 +135,7 @@ void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float*
         return;
     }
     const uint32_t passes = (k + 1023) / 1024;
-    ensure((void**)&t->d_keys, &t->keys_cap, (size_t)passes * 1024, sizeof(uint64_t));
+    ensure(t, (void**)&t->d_keys, &t->keys_cap, (size_t)passes * 1024, sizeof(uint64_t));
     for (uint32_t p = 0; p < passes; ++p) {
         const uint32_t kp = std::min(1024u, k - p * 1024);
         uint64_t* out = t->d_keys + (size_t)p * 1024;
@@ -181,8 +168,8 @@ void search_batched(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64
     uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 2, (n_tiles + 3) / 4);
     blocks = std::max(blocks, 1u);
     const uint32_t lists = blocks * 4;
-    ensure((void**)&t->d_cand, &t->cand_keys, (size_t)nq * lists * k, sizeof(uint64_t));
-    ensure((void**)&t->d_keys, &t->keys_cap, (size_t)std::max<uint32_t>(1024, nq * k), sizeof(uint64_t));
+    ensure(t, (void**)&t->d_cand, &t->cand_keys, (size_t)nq * lists * k, sizeof(uint64_t));
+    ensure(t, (void**)&t->d_keys, &t->keys_cap, (size_t)std::max<uint32_t>(1024, nq * k), sizeof(uint64_t));
     if (nq == 2) launch_batched<2>(t, d_q, k, t->d_cand, blocks, s);
     else if (nq == 4) launch_batched<4>(t, d_q, k, t->d_cand, blocks, s);
     else launch_batched<8>(t, d_q, k, t->d_cand, blocks, s);
@@ -191,7 +178,7 @@ void search_batched(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64
         launch_merge<WaveTopReg>(t->d_cand, lists, k, lists, t->d_keys, nq, cstride, k, s);
     } else {
         const uint32_t lpb = 32, mid = (lists + lpb - 1) / lpb;
-        ensure((void**)&t->d_tmp, &t->tmp_keys, (size_t)nq * mid * k, sizeof(uint64_t));
+        ensure(t, (void**)&t->d_tmp, &t->tmp_keys, (size_t)nq * mid * k, sizeof(uint64_t));
         launch_merge<WaveTopReg>(t->d_cand, lists, k, lpb, t->d_tmp, nq, cstride, (size_t)mid * k, s);
         launch_merge<WaveTopReg>(t->d_tmp, mid, k, mid, t->d_keys, nq, (size_t)mid * k, k, s);
     }
@@ -207,6 +194,14 @@ void check_search_args(const mi_knn* t, const void* q, uint32_t nq, uint32_t k, 
 }
 
 }  // namespace
+
+namespace mi {
+hipStream_t knn_own_stream(mi_knn* t) { return own_stream(t); }
+void knn_grow(mi_knn* t, uint64_t want_rows) { grow(t, want_rows); }
+void knn_search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
+    search_one(t, d_q, k, d_idx, d_dist, s);
+}
+}  // namespace mi
 
 extern "C" {
 
@@ -229,6 +224,9 @@ int mi_knn_create(uint32_t dim, int device, mi_knn** out) {
 void mi_knn_free(mi_knn* t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
+    (void)hipDeviceSynchronize();
+    t->writes.destroy();
+    t->reads.destroy();
     if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
     for (void* p : {(void*)t->table, (void*)t->d_q, (void*)t->d_cand, (void*)t->d_tmp, (void*)t->d_keys,
                     (void*)t->d_idx, (void*)t->d_dist})
@@ -269,8 +267,10 @@ int mi_knn_append(mi_knn* t, const float* rows, uint64_t n) {
         DeviceGuard g(t->device);
         own_stream(t);
         grow(t, t->rows + n);
+        t->writes.begin(t->stream);
         HIP_CHECK(hipMemcpyAsync(t->table + t->rows * t->dim, rows, n * t->dim * sizeof(float), hipMemcpyHostToDevice,
                                  t->stream));
+        t->writes.end(t->stream);
         HIP_CHECK(hipStreamSynchronize(t->stream));
         t->rows += n;
     });
@@ -284,12 +284,12 @@ int mi_knn_append_device(mi_knn* t, const float* d_rows, uint64_t n, void* strea
         std::lock_guard<std::mutex> l(t->mu);
         DeviceGuard g(t->device);
         hipStream_t s = stream ? (hipStream_t)stream : own_stream(t);
-        if (t->rows + n > t->cap) {  // growing reallocates: make the caller's stream wait for it
-            HIP_CHECK(hipStreamSynchronize(s));
-            grow(t, t->rows + n);
-        }
+        grow(t, t->rows + n);  // a reallocation waits for the handle's work in flight and copies synchronously
+        t->writes.begin(s);
         HIP_CHECK(hipMemcpyAsync(t->table + t->rows * t->dim, d_rows, n * t->dim * sizeof(float),
                                  hipMemcpyDeviceToDevice, s));
+        // `rows` counts the new rows from now on; a search on any stream waits for this event first
+        t->writes.end(s);
         t->rows += n;
     });
 }
@@ -312,6 +312,7 @@ int mi_knn_append_synthetic(mi_knn* t, uint64_t seed, uint64_t first_row, uint64
         hipLaunchKernelGGL(gen_f32_kernel, dim3(t->n_cu * 8), dim3(256), 0, t->stream, t->table + t->rows * t->dim,
                            key, first_row * t->dim, n * t->dim, scale);
         HIP_CHECK(hipGetLastError());
+        t->writes.end(t->stream);
         HIP_CHECK(hipStreamSynchronize(t->stream));
         t->rows += n;
     });
@@ -328,6 +329,7 @@ int mi_knn_get_rows(mi_knn* t, uint64_t first, uint64_t n, float* out) {
                                       (unsigned long long)t->rows);
         DeviceGuard g(t->device);
         own_stream(t);
+        t->writes.begin(t->stream);
         HIP_CHECK(hipMemcpyAsync(out, t->table + first * t->dim, n * t->dim * sizeof(float), hipMemcpyDeviceToHost,
                                  t->stream));
         HIP_CHECK(hipStreamSynchronize(t->stream));
@@ -370,6 +372,7 @@ int mi_knn_save(mi_knn* t, const char* path) {
         const size_t total = (size_t)t->rows * t->dim * sizeof(float);
         if (total == 0) return;
         PinnedBuf buf(std::min(total, IO_CHUNK));
+        t->writes.begin(t->stream);
         for (size_t off = 0; off < total; off += IO_CHUNK) {
             const size_t n = std::min(IO_CHUNK, total - off);
             HIP_CHECK(hipMemcpyAsync(buf.p, (const char*)t->table + off, n, hipMemcpyDeviceToHost, t->stream));
@@ -415,8 +418,11 @@ int mi_knn_search_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, u
         std::lock_guard<std::mutex> l(t->mu);
         DeviceGuard g(t->device);
         hipStream_t s = stream ? (hipStream_t)stream : own_stream(t);
+        t->writes.begin(s);
+        t->reads.begin(s);
         for (uint32_t u = 0; u < nq; ++u)
             search_one(t, d_q + (size_t)u * t->dim, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
+        t->reads.end(s);
     });
 }
 
@@ -428,6 +434,8 @@ int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint3
         std::lock_guard<std::mutex> l(t->mu);
         DeviceGuard g(t->device);
         hipStream_t s = stream ? (hipStream_t)stream : own_stream(t);
+        t->writes.begin(s);
+        t->reads.begin(s);
         uint32_t u = 0;
         while (u < nq) {
             const uint32_t left = nq - u;
@@ -436,6 +444,7 @@ int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint3
             else search_batched(t, d_q + (size_t)u * t->dim, b, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
             u += b;
         }
+        t->reads.end(s);
     });
 }
 
@@ -449,8 +458,10 @@ int mi_knn_search(mi_knn* t, const float* q, uint32_t nq, uint32_t k, uint64_t* 
         // groups of up to 16 queries: one upload, table passes of 8 / 4 / 2 queries where the register
         // path applies (k <= 64; same arithmetic per query as the single-query pass), one readback
         constexpr uint32_t GROUP = 16;
-        ensure((void**)&t->d_idx, &t->idx_cap, (size_t)GROUP * k, sizeof(uint64_t));
-        ensure((void**)&t->d_dist, &t->dist_cap, (size_t)GROUP * k, sizeof(float));
+        ensure(t, (void**)&t->d_idx, &t->idx_cap, (size_t)GROUP * k, sizeof(uint64_t));
+        ensure(t, (void**)&t->d_dist, &t->dist_cap, (size_t)GROUP * k, sizeof(float));
+        t->writes.begin(t->stream);
+        t->reads.begin(t->stream);
         for (uint32_t u0 = 0; u0 < nq; u0 += GROUP) {
             const uint32_t ng = std::min(GROUP, nq - u0);
             HIP_CHECK(hipMemcpyAsync(t->d_q, q + (size_t)u0 * t->dim, (size_t)ng * t->dim * sizeof(float),
@@ -469,6 +480,7 @@ int mi_knn_search(mi_knn* t, const float* q, uint32_t nq, uint32_t k, uint64_t* 
                                      t->stream));
             HIP_CHECK(hipStreamSynchronize(t->stream));
         }
+        t->reads.pending = false;
     });
 }
 

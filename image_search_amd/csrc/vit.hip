@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "common.h"
+#include "handles.h"
 #include "../../include/mi355clip_ops.h"
 #include "preprocess_kernels.h"
 #include "vit_kernels.h"
@@ -172,60 +173,7 @@ inline uint16_t f32_to_bf16_host(float f) {  // round to nearest even, NaN stays
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-// ------------------------------------------------------------------ model
-struct Layer {
-    float *ln1w, *ln1b, *ln2w, *ln2b;
-    void *wqkv, *wo, *w1, *w2;  // T [N][K]
-    float *bqkv, *bo, *b1, *b2;
-};
-
 }  // namespace
-
-struct mi_clip {
-    int device = 0, precision = 0;
-    int image = 0, patch = 0, grid = 0, S = 0, D = 0, L = 0, H = 0, FF = 0, E = 0, Kp = 0;
-    float eps = 1e-5f;
-    std::vector<void*> allocs;
-    float *cls = nullptr, *pos = nullptr, *pre_w = nullptr, *pre_b = nullptr, *post_w = nullptr, *post_b = nullptr,
-          *proj = nullptr;
-    void* wpatch = nullptr;  // T [D][Kp]
-    std::vector<Layer> layers;
-    // workspace for `cap` images
-    size_t cap = 0;
-    std::vector<void*> ws;
-    float *d_in = nullptr, *d_in2 = nullptr, *d_out = nullptr, *d_out2 = nullptr;
-    // activations: set 0 serves a whole chunk; set 1 exists so that two half-chunks can run as two
-    // independent streams (see forward()).
-    struct Act {
-        float *patch = nullptr, *x = nullptr;
-        void *col = nullptr, *y = nullptr, *qkv = nullptr, *h = nullptr;
-        bf16_t *delta = nullptr, *delta2 = nullptr;  // bf16 path: out_proj / fc2 outputs, added to x by LayerNorm
-        // last layer, CLS rows only (n rows, padded to 256): context, residual, LN output, MLP hidden, deltas
-        void *c_ctx = nullptr, *c_y = nullptr, *c_h = nullptr;
-        float* c_x = nullptr;
-        bf16_t *c_d1 = nullptr, *c_d2 = nullptr;
-    } act[4];
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    int parts = 2;  // MI_CLIP_PARTS: sub-chunks run as independent streams
-    int n_cu = 256;
-    uint8_t* d_rgb = nullptr;
-    // text tower (mi_clip_load_text): token table, device copies of the ids and of the EOS rows
-    bool text = false;
-    int vocab = 0;
-    float* tok = nullptr;
-    int *d_ids = nullptr, *d_rows = nullptr;
-    size_t text_cap = 0;
-    // mi_clip_embed_images: two upload buffers for decoded images, the resize intermediate, a copy stream
-    uint8_t* d_img_src[2] = {nullptr, nullptr};
-    float* d_img_tmp = nullptr;
-    size_t img_src_cap = 0, img_tmp_cap = 0;
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
-    hipStream_t stream = nullptr;
-    size_t max_batch = 256;
-    std::mutex mu;
-};
 
 namespace {
 
@@ -381,6 +329,7 @@ hipStream_t own_stream(mi_clip* m) {
 void ensure_workspace(mi_clip* m, size_t n) {
     if (n <= m->cap) return;
     own_stream(m);
+    m->order.sync();  // enqueued forwards still use the buffers freed below
     for (void* p : m->ws) HIP_CHECK(hipFree(p));
     m->ws.clear();
     m->cap = 0;
@@ -396,7 +345,8 @@ void ensure_workspace(mi_clip* m, size_t n) {
     m->d_in = (float*)bytes(n * px * 4);
     m->d_in2 = (float*)bytes(n * px * 4);  // mi_clip_embed: upload of chunk i+1 under the forward of chunk i
     m->d_rgb = (uint8_t*)bytes(n * px);
-    for (int a = 0; a < 4; ++a) {
+    const int sets = (m->precision == MI_PRECISION_BF16) ? std::max(1, m->parts) : 1;
+    for (int a = 0; a < sets; ++a) {
         const size_t na = a == 0 ? n : (n + 1) / 2;
         const size_t Ma = pad256(na * m->S), Pa = pad256(na * (m->S - 1));
         if (na == 0) continue;
@@ -440,14 +390,14 @@ void gemm_p(int precision, const void* X, const void* W, const float* bias, void
                                (float*)out, N, K, ldo);
     } else {
         if (K % 64 != 0) fail(MI_ERR_UNSUPPORTED, "GEMM K=%d is not a multiple of 64", K);
-        static bool attr_done[4] = {false, false, false, false};
+        static DevOnce once;  // one per EPI instantiation
         if (EPI == EPI_STORE_F32 || EPI == EPI_BIAS_RESID) {
             auto kern = gemm_bf16_kernel<EPI, float>;
-            if (!attr_done[EPI]) { HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_done[EPI] = true; }
+            allow_lds_once(once, kern, 65536);
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 65536, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, N, K, ldo);
         } else {
             auto kern = gemm_bf16_kernel<EPI, bf16_t>;
-            if (!attr_done[EPI]) { HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_done[EPI] = true; }
+            allow_lds_once(once, kern, 65536);
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 65536, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, N, K, ldo);
         }
     }
@@ -465,26 +415,16 @@ void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) {
         if (big) {
             constexpr int LDS = 131072 + 18432 + 2048;
-            // Default (3): two wave groups one barrier apart (gemm_bf16_pp_kernel, 214 VGPRs): -12 % per
-            // GEMM alone, 46.9 vs 49.9 ms per 256 images in the tower.  MI_GEMM_V=1: the one-barrier form
-            // (186 VGPRs), kept for A/B.
-            static const int ver = std::getenv("MI_GEMM_V") ? std::atoi(std::getenv("MI_GEMM_V")) : 3;
-            auto kern = ver == 1 ? gemm_bf16_persist_kernel<EPI, bf16_t> : gemm_bf16_pp_kernel<EPI, bf16_t>;
-            static bool done = false;
-            if (!done) {
-                HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-                HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<EPI, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-                done = true;
-            }
+            auto kern = gemm_bf16_pp_kernel<EPI, bf16_t>;
+            static DevOnce once;
+            allow_lds_once(once, kern, LDS);
             const int n_tiles = (int)((Mp / 256) * (N / 256));
             const int grid = std::min(n_tiles * 4, m->n_cu);
             // a short last round (<= a quarter of the CUs busy) is cut into quadrant tasks
             const int left = n_tiles % grid;
-            static const bool split_tail = !(std::getenv("MI_GEMM_SPLIT") && std::atoi(std::getenv("MI_GEMM_SPLIT")) == 0);  // A/B hook
-            const int n_full = (split_tail && left > 0 && left * 4 <= grid) ? n_tiles - left : n_tiles;
-            static const int l2_order = std::getenv("MI_GEMM_ORDER") ? std::atoi(std::getenv("MI_GEMM_ORDER")) : 0;  // 1 = XCD-patch order (47.4 vs 46.1 ms in the tower: off)
+            const int n_full = (m->split_tail && left > 0 && left * 4 <= grid) ? n_tiles - left : n_tiles;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, (int)Mp, N,
-                               K, ldo, n_tiles, n_full, l2_order);
+                               K, ldo, n_tiles, n_full, 0);
             HIP_CHECK(hipGetLastError());
             return;
         }
@@ -531,8 +471,8 @@ void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, 
         const int sp = (m->S + 31) / 32 * 32;
 #define MI_ATTN(SP, SC)                                                                                              \
     {                                                                                                                \
-        static bool done = false;                                                                                    \
-        if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)attn_bf16_kernel<SP, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, SP * 256)); done = true; } \
+        static DevOnce once;                                                                                         \
+        allow_lds_once(once, attn_bf16_kernel<SP, SC>, SP * 256);                                                    \
         hipLaunchKernelGGL((attn_bf16_kernel<SP, SC>), dim3(blocks), dim3(256), SP * 256, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, first_tile_only ? 1 : 0); \
     }
         if (m->S == 257) MI_ATTN(288, 257)       // ViT-L/14, ViT-H/14 @224
@@ -596,9 +536,8 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     // The pooled output is the CLS row (modeling_clip.py:641-651), so behind the LAST layer's attention
     // only that row of every image is live: its context row is gathered and out_proj, LN2, the MLP and
     // the head run on n rows instead of n*S (same arithmetic per row, so the same bits; the reference's
-    // graph computes the other rows and discards them).  MI_CLIP_FULL_LAST=1 keeps the full last layer.
-    const char* fl = std::getenv("MI_CLIP_FULL_LAST");  // read per call: the parity test toggles it
-    const bool full_last = fl && std::atoi(fl) != 0;
+    // graph computes the other rows and discards them).  Option "full_last" keeps the full last layer.
+    const bool full_last = m->full_last;
     for (size_t li = 0; li < m->layers.size(); ++li) {
         const Layer& ly = m->layers[li];
         const bool last = !full_last && li + 1 == m->layers.size();
@@ -687,6 +626,7 @@ void ensure_copy_stream(mi_clip* m) {
 void ensure_text_workspace(mi_clip* m, size_t n) {
     if (n <= m->text_cap) return;
     own_stream(m);
+    m->order.sync();
     for (void* p : m->ws) HIP_CHECK(hipFree(p));
     m->ws.clear();
     m->text_cap = 0;
@@ -736,6 +676,7 @@ void free_model(mi_clip* m) {
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     for (auto& a : m->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
+    m->order.destroy();
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     for (auto& e : m->ev_join) if (e) (void)hipEventDestroy(e);
     if (m->copy_stream) { (void)hipStreamSynchronize(m->copy_stream); (void)hipStreamDestroy(m->copy_stream); }
@@ -752,7 +693,39 @@ void free_model(mi_clip* m) {
 
 }  // namespace
 
+namespace mi {
+hipStream_t clip_own_stream(mi_clip* m) { return own_stream(m); }
+void clip_ensure_workspace(mi_clip* m, size_t n) { ensure_workspace(m, n); }
+void clip_ensure_copy_stream(mi_clip* m) { ensure_copy_stream(m); }
+void clip_forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t s) { forward(m, d_img, n, d_out, s); }
+}  // namespace mi
+
 extern "C" {
+
+int mi_clip_set_option(mi_clip* m, const char* key, int value) {
+    return guarded([&] {
+        if (!m || !key) fail(MI_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> l(m->mu);
+        DeviceGuard g(m->device);
+        const std::string k(key);
+        if (k == "full_last") m->full_last = value != 0;
+        else if (k == "split_tail") m->split_tail = value != 0;
+        else if (k == "max_batch") {
+            if (value < 1) fail(MI_ERR_INVALID, "max_batch must be >= 1");
+            m->max_batch = (size_t)value;
+        } else if (k == "parts") {
+            if (value < 1 || value > 4) fail(MI_ERR_INVALID, "parts must be 1..4");
+            if (m->text) fail(MI_ERR_INVALID, "the text tower runs as one stream");
+            if (value != m->parts) {  // the activation sets are sized per part: rebuild on next use
+                m->order.sync();
+                for (void* p : m->ws) HIP_CHECK(hipFree(p));
+                m->ws.clear();
+                m->cap = 0;
+                m->parts = value;
+            }
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, split_tail, max_batch, parts)", key);
+    });
+}
 
 int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** out) {
     mi_clip* m = nullptr;
@@ -772,6 +745,8 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
         for (auto& e : m->ev_join) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (const char* e = std::getenv("MI_CLIP_PARTS")) m->parts = std::min(4, std::max(1, std::atoi(e)));
+        if (const char* e = std::getenv("MI_CLIP_FULL_LAST")) m->full_last = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MI_GEMM_SPLIT")) m->split_tail = std::atoi(e) != 0;
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         m->n_cu = prop.multiProcessorCount;
@@ -822,10 +797,12 @@ int mi_clip_embed_text(mi_clip* m, const int32_t* input_ids, size_t n, float* ou
         ensure_text_workspace(m, chunk);
         for (size_t i = 0; i < n; i += chunk) {
             const size_t c = std::min(chunk, n - i);
+            m->order.begin(m->stream);
             HIP_CHECK(hipMemcpyAsync(m->d_ids, input_ids + i * m->S, c * m->S * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
             forward_text(m, c, m->stream);
             HIP_CHECK(hipMemcpyAsync(out + i * m->E, m->d_out, c * m->E * 4, hipMemcpyDeviceToHost, m->stream));
             HIP_CHECK(hipStreamSynchronize(m->stream));
+            m->order.pending = false;
         }
     });
 }
@@ -849,11 +826,14 @@ int mi_clip_embed_device(mi_clip* m, const float* d_nchw, size_t n, float* d_out
         hipStream_t s = stream ? (hipStream_t)stream : own_stream(m);
         const size_t px = (size_t)m->image * m->image * 3;
         const size_t chunk = std::min(n, m->max_batch);
-        if (chunk > m->cap) { HIP_CHECK(hipStreamSynchronize(s)); ensure_workspace(m, chunk); }
+        ensure_workspace(m, chunk);
+        // the handle's work runs in call order whatever stream each call names (one workspace per handle)
+        m->order.begin(s);
         for (size_t i = 0; i < n; i += chunk) {
             const size_t c = std::min(chunk, n - i);
             forward(m, d_nchw + i * px, c, d_out + i * m->E, s);
         }
+        m->order.end(s);
     });
 }
 
@@ -874,6 +854,7 @@ int mi_clip_embed(mi_clip* m, const float* nchw, size_t n, float* out) {
         float* din[2] = {m->d_in, m->d_in2};
         float* dout[2] = {m->d_out, m->d_out2};
         const size_t nchunks = (n + chunk - 1) / chunk;
+        m->order.begin(m->stream);
         auto upload = [&](size_t ci) {
             const size_t i = ci * chunk, c = std::min(chunk, n - i);
             const int b = (int)(ci & 1);
@@ -892,6 +873,7 @@ int mi_clip_embed(mi_clip* m, const float* nchw, size_t n, float* out) {
             HIP_CHECK(hipMemcpyAsync(out + i * m->E, dout[b], c * m->E * 4, hipMemcpyDeviceToHost, m->stream));
         }
         HIP_CHECK(hipStreamSynchronize(m->stream));
+        m->order.pending = false;
     });
 }
 
@@ -906,6 +888,7 @@ int mi_clip_embed_rgb8(mi_clip* m, const uint8_t* rgb8, size_t n, float* out) {
         const size_t plane = (size_t)m->image * m->image, px = plane * 3;
         const size_t chunk = std::min(n, m->max_batch);
         ensure_workspace(m, chunk);
+        m->order.begin(m->stream);
         for (size_t i = 0; i < n; i += chunk) {
             const size_t c = std::min(chunk, n - i);
             HIP_CHECK(hipMemcpyAsync(m->d_rgb, rgb8 + i * px, c * px, hipMemcpyHostToDevice, m->stream));
@@ -914,6 +897,7 @@ int mi_clip_embed_rgb8(mi_clip* m, const uint8_t* rgb8, size_t n, float* out) {
             forward(m, m->d_in, c, m->d_out, m->stream);
             HIP_CHECK(hipMemcpyAsync(out + i * m->E, m->d_out, c * m->E * 4, hipMemcpyDeviceToHost, m->stream));
             HIP_CHECK(hipStreamSynchronize(m->stream));
+            m->order.pending = false;
         }
     });
 }
@@ -957,6 +941,7 @@ int mi_clip_embed_images(mi_clip* m, const uint8_t* const* rgb8, const uint32_t*
             m->img_tmp_cap = max_tmp;
         }
         ensure_copy_stream(m);
+        m->order.begin(m->stream);
         for (size_t i0 = 0; i0 < n; i0 += chunk) {
             const size_t c = std::min(chunk, n - i0);
             for (size_t j = 0; j < c; ++j) {
@@ -974,6 +959,7 @@ int mi_clip_embed_images(mi_clip* m, const uint8_t* const* rgb8, const uint32_t*
             forward(m, m->d_in, c, m->d_out, m->stream);
             HIP_CHECK(hipMemcpyAsync(out + i0 * m->E, m->d_out, c * m->E * 4, hipMemcpyDeviceToHost, m->stream));
             HIP_CHECK(hipStreamSynchronize(m->stream));
+            m->order.pending = false;
         }
     });
 }

@@ -648,24 +648,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
 //   + half-tile pipeline, counted vmcnt   900 / 850 / 950 / 1100
 //   + persistent, async row-wise epilogue 1060 / 960 / 1070 / 1100
 //   + split last round                    1060 / 1040 / 1090 / 1200
-// Visit index -> tile, L2-aware.  Workgroups of one XCD (consecutive logical ids after xcd_remap)
-// run, round after round, an 8 (m) x 4 (n) patch of tiles: the four W tiles stay in that XCD's L2
-// across rounds and each X panel is fetched by 4 workgroups of one XCD at about the same time,
-// instead of every XCD streaming every W tile every round.  Full rounds only (v < n_full); the
-// leftover tiles keep their position.  Returns tm in .x, tn in .y.
-struct TileMN { int tm, tn; };
-__device__ __forceinline__ TileMN tile_of_visit(int v, int G, int nt, int mt, int n_full) {
-    if (n_full < 0) return {v / nt, v % nt};  // natural order (debug / A-B)
-    int seq = v;
-    const int rounds = n_full / G;  // complete rounds of G tiles; anything after keeps its position
-    if (v < rounds * G && (G & 7) == 0) {
-        const int per = G >> 3, lbv = v % G, r = v / G;
-        seq = (lbv / per) * (rounds * per) + r * per + (lbv % per);
-    }
-    const int np = (nt & 3) == 0 ? 4 : nt;  // n-tiles per group
-    const int grp = seq / (mt * np), rem = seq % (mt * np);
-    return {rem / np, grp * np + rem % np};
-}
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
@@ -676,271 +658,8 @@ __device__ __forceinline__ void glds16_buf(rsrc_t r, uint32_t voff, uint32_t sof
                                              0, 0);
 }
 
-template <int EPI, typename TO>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_persist_kernel(const bf16_t* __restrict__ X,
-                                                                   const bf16_t* __restrict__ W,
-                                                                   const float* __restrict__ bias,
-                                                                   void* __restrict__ out, int M, int N, int K,
-                                                                   int ldo, int n_tiles, int n_full, int l2_order) {
-    static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU, "the persistent form stores bf16 with bias");
-    static_assert(sizeof(TO) == 2, "bf16 output");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 128 KiB staging + 18 KiB patches + 2 KiB bias
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3, g = lane >> 4, l15 = lane & 15;
-    const int nt = N / 256;
-    const int G = gridDim.x;
-    const int lb = (int)xcd_remap(blockIdx.x, G);
-    int tile = lb;
-
-    const uint32_t Kb = (uint32_t)K * 2;
-    const rsrc_t xr = make_rsrc(X, (uint32_t)M * Kb);
-    const rsrc_t wr = make_rsrc(W, (uint32_t)N * Kb);
-    const rsrc_t orr = make_rsrc(out, (uint32_t)M * (uint32_t)ldo * (uint32_t)sizeof(TO));
-    const int rr = lane >> 3, p = lane & 7;
-    const uint32_t x_lane = (uint32_t)rr * Kb + 16 * (p ^ rr);  // per-lane part (same for X and W)
-    const uint32_t x_wave = (uint32_t)(128 * (wave >> 2) + 16 * (wave & 3)) * Kb;
-    const uint32_t w_wave = (uint32_t)(64 * (wave >> 1) + 16 * (wave & 1)) * Kb;
-    // half-tile i: 0 = XH0, 1 = WH0, 2 = WH1, 3 = XH1;  xs / ws = scalar byte offset of the tile's first row
-    auto stage_half = [&](int buf, uint32_t xs, uint32_t ws, int kt, int i) {
-        const bool is_x = (i == 0 || i == 3);
-        const int h = (i >= 2) ? 1 : 0;
-        unsigned char* dst = smem + buf * 65536 + (is_x ? 0 : 32768) + h * 16384 + wave * 2048;
-        const uint32_t so = (is_x ? xs + x_wave + 64u * h * Kb : ws + w_wave + 32u * h * Kb) + (uint32_t)kt * 128u;
-        glds16_buf(is_x ? xr : wr, x_lane, so, dst);
-        glds16_buf(is_x ? xr : wr, x_lane, so + 8u * Kb, dst + 1024);
-    };
-
-    const int sw = lane & 7;
-    const int x_off = (wm * 64 + l15) * 128;
-    const int w_off = 32768 + (wn * 32 + l15) * 128;
-    bf16x8 xf[2][4], wf[2][2];
-    v4f acc[4][8];
-    auto load_x = [&](const unsigned char* base, int mh) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                xf[ks][i] = *reinterpret_cast<const bf16x8*>(base + x_off + mh * 16384 + i * 2048 + (((4 * ks + g) ^ sw) << 4));
-    };
-    auto load_w = [&](const unsigned char* base, int nh) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                wf[ks][i] = *reinterpret_cast<const bf16x8*>(base + w_off + nh * 16384 + i * 2048 + (((4 * ks + g) ^ sw) << 4));
-    };
-#ifdef MI_GEMM_SETPRIO
-#define MI_PRIO(x) __builtin_amdgcn_s_setprio(x);
-#else
-#define MI_PRIO(x)
-#endif
-#if defined(GEMM_ABL) && GEMM_ABL == 1
-#define MI_MODE1_CNT 5   /* no stores in the queue: 4 + bias DMA */
-#else
-#define MI_MODE1_CNT 21
-#endif
-#ifndef MI_ST_AUX
-#define MI_ST_AUX 0
-#endif
-#define MI_STR2(x) #x
-#define MI_STR(x) MI_STR2(x)
-#define MI_QUADRANT(MH, NH)                                                                               \
-    MI_PRIO(1)                                                                                            \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
-    _Pragma("unroll") for (int im = 0; im < 4; ++im)                                                      \
-    _Pragma("unroll") for (int in = 0; in < 2; ++in)                                                      \
-        acc[2 * NH + in][4 * MH + im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
-            wf[ks][in], xf[ks][im], acc[2 * NH + in][4 * MH + im], 0, 0, 0);                               \
-    MI_PRIO(0)
-// wait mode (wave-uniform): 0 steady state, 1 first K tile after an epilogue (16 stores still
-// counted), 2 the very last K tile of this workgroup (nothing more is staged: 4, 2, 0)
-#define MI_SYNC(PH)                                                                            \
-    if (mode == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                             \
-    else if (mode == 1) asm volatile("s_waitcnt vmcnt(" MI_STR(MI_MODE1_CNT) ")" ::: "memory");     \
-    else if (PH == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                          \
-    else if (PH == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                          \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
-    __builtin_amdgcn_s_barrier();
-#define MI_STAGE(i) if (do_stage) stage_half(b ^ 1, s_x, s_w, s_kt, i);
-
-    // the wave's 64 bias values travel by LDS-DMA too (no VGPR destination: hipcc would drain the
-    // whole queue with vmcnt(0) at the first use of an ordinary load issued beside LDS-DMA)
-    const rsrc_t br = make_rsrc(bias, (uint32_t)N * 4u);
-    unsigned char* bias_lds = smem + 131072 + 18432 + wave * 256;
-    auto stage_bias = [&](int tn) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (__attribute__((address_space(3))) void*)bias_lds, 4,
-                                                 (uint32_t)lane * 4u, (uint32_t)(tn * 256 + wn * 64) * 4u, 0, 0);
-    };
-    const int nk = K / 64;
-    int b = 0, kt = 0;
-    const int mt = M / 256;
-    TileMN cur = tile_of_visit(tile, G, nt, mt, l2_order ? n_full : -1);
-    uint32_t xs = (uint32_t)cur.tm * 256u * Kb, ws = (uint32_t)cur.tn * 256u * Kb;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[a][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-    if (tile < n_full) {
-    stage_bias(cur.tn);  // oldest op of the stream
-#pragma unroll
-    for (int i = 0; i < 4; ++i) stage_half(0, xs, ws, 0, i);
-    bool after_epilogue = false;
-    // per-lane part of the output offset: row wm*128 + (lane>>3), column wn*64 + 8*(lane&7)
-    const uint32_t o_lane = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
-
-    for (;;) {
-        const bool last_kt = (kt == nk - 1);
-        const int next = tile + G;
-        const bool has_next = next < n_full;
-        // what the four phases of this K tile stage: the next K tile of this tile, or K tile 0 of the next
-        const TileMN nxt = tile_of_visit(next, G, nt, mt, l2_order ? n_full : -1);
-        const uint32_t s_x = last_kt ? (uint32_t)nxt.tm * 256u * Kb : xs;
-        const uint32_t s_w = last_kt ? (uint32_t)nxt.tn * 256u * Kb : ws;
-        const int s_kt = last_kt ? 0 : kt + 1;
-        const bool do_stage = !last_kt || has_next;
-        const int mode = !do_stage ? 2 : ((after_epilogue && kt == 0) ? 1 : 0);
-        {
-            const unsigned char* base = smem + b * 65536;
-            MI_SYNC(0) MI_STAGE(0) load_x(base, 0); load_w(base, 0); MI_QUADRANT(0, 0)
-            MI_SYNC(1) MI_STAGE(1) load_w(base, 1); MI_QUADRANT(0, 1)
-            MI_SYNC(2) MI_STAGE(2) load_x(base, 1); MI_QUADRANT(1, 1)
-            MI_STAGE(3) load_w(base, 0); MI_QUADRANT(1, 0)
-            b ^= 1;
-        }
-        if (!last_kt) { ++kt; continue; }
-
-#if defined(GEMM_ABL) && GEMM_ABL == 2  // timing only: no epilogue at all
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 8; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
-        if (!has_next) break;
-        tile = next; cur = nxt; xs = s_x; ws = s_w; kt = 0; after_epilogue = false;
-        continue;
-#endif
-        // epilogue: each 16-row m-tile of the wave's slab goes through a wave-private LDS patch
-        // (16 rows x 144 B, beyond the two staging buffers) so that the global stores are whole
-        // 128-byte row segments, 16 bytes per lane: exactly 16 stores per lane, left in flight.
-        __builtin_amdgcn_sched_barrier(0);
-        const int n0 = cur.tn * 256;
-#if defined(GEMM_ABL) && GEMM_ABL == 3  // timing only: every tile stored over tile (lb % 8, 0): L2-resident
-        const uint32_t o_tile = ((uint32_t)(lb & 7) * 256u * (uint32_t)ldo + 0u * (uint32_t)n0) * 2u;
-#else
-        const uint32_t o_tile = ((uint32_t)cur.tm * 256u * (uint32_t)ldo + (uint32_t)n0) * 2u;
-#endif
-        v4f bv[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bv[ni] = *reinterpret_cast<const v4f*>(bias_lds + (ni * 16 + 4 * g) * 4);
-        unsigned char* patch = smem + 131072 + wave * 2304;
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                v4f v = acc[ni][mi] + bv[ni];
-                acc[ni][mi] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-                if constexpr (EPI == EPI_BIAS_QGELU) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = quick_gelu<true>(v[c]);
-                }
-                v2u pk;
-                pk.x = pack2bf(v[0], v[1]);
-                pk.y = pack2bf(v[2], v[3]);
-                *reinterpret_cast<v2u*>(patch + l15 * 144 + (ni * 16 + 4 * g) * 2) = pk;
-            }
-            // lanes exchange data through the patch: the ds_writes must have landed before any lane's
-            // ds_read, and the reads must have returned before the next m-tile's writes (without these
-            // waits 1e-6 of the outputs came out stale under store pressure — measured, N >= 3072)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = j * 8 + (lane >> 3);
-                const v4u d = *reinterpret_cast<const v4u*>(patch + row * 144 + (lane & 7) * 16);
-                const uint32_t so = o_tile + (uint32_t)(mi * 16 + j * 8) * (uint32_t)ldo * 2u;
-#if defined(GEMM_ABL) && GEMM_ABL == 1  // timing only: no output stores
-                asm volatile("" ::"v"(d), "s"(so));
-#else
-                __builtin_amdgcn_raw_buffer_store_b128(d, orr, o_lane, so, MI_ST_AUX);
-#endif
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!has_next) break;
-        tile = next;
-        cur = nxt;
-        xs = s_x; ws = s_w;
-        kt = 0;
-        after_epilogue = true;
-        stage_bias(cur.tn);  // one more counted op between the stores and the next K tile
-    }
-    }  // full tiles
-
-    // ---- the last, partial round: tiles [n_full, n_tiles) are cut into four quadrant tasks each
-    // (64 rows per wave-row x 32 columns per wave-column = quadrant (mh, nh) of the tile), so that
-    // up to 4x more CUs share it.  A task is the (0,0) quadrant of a virtual tile whose X / W rows
-    // start 64*mh / 32*nh rows further: only XH0 / WH0 are staged (2 K tiles ahead, both buffers).
-    const int n_tasks = (n_tiles - n_full) * 4;
-    for (int task = lb; task < n_tasks; task += G) {
-        const int t = n_full + (task >> 2), mh = (task >> 1) & 1, nh = task & 1;
-        const TileMN tt = tile_of_visit(t, G, nt, mt, l2_order ? n_full : -1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const uint32_t txs = (uint32_t)tt.tm * 256u * Kb + 64u * mh * Kb, tws = (uint32_t)tt.tn * 256u * Kb + 32u * nh * Kb;
-        stage_bias(tt.tn);
-        stage_half(0, txs, tws, 0, 0); stage_half(0, txs, tws, 0, 1);
-        if (nk > 1) { stage_half(1, txs, tws, 1, 0); stage_half(1, txs, tws, 1, 1); }
-        for (int kq = 0; kq < nk; ++kq) {
-            if (kq + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const unsigned char* base = smem + (kq & 1) * 65536;
-            load_x(base, 0); load_w(base, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // every wave has its fragments: the buffer may be refilled
-            if (kq + 2 < nk) { stage_half(kq & 1, txs, tws, kq + 2, 0); stage_half(kq & 1, txs, tws, kq + 2, 1); }
-            MI_QUADRANT(0, 0)
-        }
-        // epilogue of the 64 x 32 quadrant of this wave: 4 m-tiles x 2 n-tiles, 64-byte row pieces
-        __builtin_amdgcn_sched_barrier(0);
-        v4f bq[2];
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) bq[ni] = *reinterpret_cast<const v4f*>(bias_lds + (32 * nh + ni * 16 + 4 * g) * 4);
-        unsigned char* patch = smem + 131072 + wave * 2304;
-        const uint32_t q_tile = ((uint32_t)tt.tm * 256u * (uint32_t)ldo + (uint32_t)(tt.tn * 256)) * 2u;
-        const uint32_t q_lane = ((uint32_t)(wm * 128 + 64 * mh + (lane >> 2)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 32 * nh + 8 * (lane & 3))) * 2u;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                v4f v = acc[ni][mi] + bq[ni];
-                acc[ni][mi] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-                if constexpr (EPI == EPI_BIAS_QGELU) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = quick_gelu<true>(v[c]);
-                }
-                v2u pk;
-                pk.x = pack2bf(v[0], v[1]);
-                pk.y = pack2bf(v[2], v[3]);
-                *reinterpret_cast<v2u*>(patch + l15 * 144 + (ni * 16 + 4 * g) * 2) = pk;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            const v4u d = *reinterpret_cast<const v4u*>(patch + (lane >> 2) * 144 + (lane & 3) * 16);
-            __builtin_amdgcn_raw_buffer_store_b128(d, orr, q_lane, q_tile + (uint32_t)(mi * 16) * (uint32_t)ldo * 2u, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#undef MI_QUADRANT
-#undef MI_SYNC
-#undef MI_STAGE
-}
-
 // ------------------------------------------------------------------ bf16 GEMM, persistent, two staggered wave groups
-// Same tile (256 x 256 x 64), LDS image and epilogue as gemm_bf16_persist_kernel, other schedule:
+// Tile (256 x 256 x 64), LDS image and epilogue as described above; the schedule:
 // the two wave rows (waves 0-3 / 4-7: one wave of each per SIMD) run ONE BARRIER APART, so that in
 // every barrier interval one group issues MFMAs while the other fetches its next fragments from LDS
 // and issues the next half-tiles' LDS-DMA -- the LDS latency and bandwidth that the one-barrier form

@@ -119,6 +119,83 @@ class EmbeddingTable:
         check(fn(self._h, d_q, nq, k, d_idx, d_dist, stream))
 
 
+class PinnedBuffer:
+    """Page-locked host memory (mi_host_alloc) viewed as a numpy array: upload buffers of the
+    fused pipeline (asynchronous H2D needs pinned memory)."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.shape = tuple(int(x) for x in shape)
+        self.dtype = np.dtype(dtype)
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._p = c_vp()
+        check(lib().mi_host_alloc(nbytes, ctypes.byref(self._p)))
+        buf = (ctypes.c_char * nbytes).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype).reshape(self.shape)
+
+    def close(self):
+        if getattr(self, "_p", None) and self._p.value:
+            self.array = None
+            lib().mi_host_free(self._p)
+            self._p = c_vp()
+
+    __del__ = close
+
+
+class Pipeline:
+    """The scan-loop body (clip.rs:107-137) and the query (search.rs:70-86) fused on HIP streams
+    (mi_pipeline_*): `ingest` uploads, embeds and inserts a chunk without a readback; `query`
+    scans on a second stream under the next chunk's forward; `sync` delivers the results."""
+
+    def __init__(self, model, table: "EmbeddingTable"):
+        self._h = c_vp()
+        self.model, self.table = model, table  # borrowed: keep them alive
+        self._pending = []
+        check(lib().mi_pipeline_create(model._h, table._h, ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mi_pipeline_free(self._h)
+            self._h = c_vp()
+            self._pending = []
+
+    __del__ = close
+
+    def ingest(self, nchw: np.ndarray) -> int:
+        """nchw: [n,3,H,W] f32 (a PinnedBuffer.array makes the upload asynchronous; the array must stay
+        untouched until the next ingest / sync returns).  Returns the id of the chunk's first row."""
+        x = nchw if (nchw.dtype == np.float32 and nchw.flags.c_contiguous) else np.ascontiguousarray(nchw, np.float32)
+        first = ctypes.c_uint64()
+        check(lib().mi_pipeline_ingest(self._h, x.ctypes.data, x.shape[0], ctypes.byref(first)))
+        return first.value
+
+    def query(self, reference: np.ndarray, k: int = K_REFERENCE):
+        """Enqueue `embedding <|k|> $reference`; returns (ids, distances) arrays that are filled by sync()."""
+        q = _f32(reference).reshape(-1)
+        idx = np.full(k, NO_ID, np.uint64)
+        dist = np.full(k, np.inf, np.float32)
+        check(lib().mi_pipeline_query(self._h, q.ctypes.data, k, idx.ctypes.data, dist.ctypes.data))
+        self._pending.append((idx, dist))  # the library writes into them at sync: keep them alive
+        return idx, dist
+
+    def sync(self):
+        check(lib().mi_pipeline_sync(self._h))
+        self._pending = []
+
+    def drain(self, leave_pending: int = 0):
+        """Deliver finished queries (oldest first) until at most `leave_pending` remain pending."""
+        check(lib().mi_pipeline_drain(self._h, leave_pending))
+        if leave_pending == 0:
+            self._pending = []
+        else:
+            self._pending = self._pending[-leave_pending:]
+
+    def stats(self, reset: bool = False):
+        """(forwards, ms in forwards, scans, ms in scans) measured by events on the pipeline's streams."""
+        out = (ctypes.c_double * 4)()
+        check(lib().mi_pipeline_stats(self._h, out, 1 if reset else 0))
+        return tuple(out)
+
+
 def merge_candidates(idx_lists: np.ndarray, dist_lists: np.ndarray, k: int):
     """Global top-k of `lists` per-shard candidate lists (same ordering rule)."""
     i = np.ascontiguousarray(idx_lists, np.uint64).reshape(-1)

@@ -19,6 +19,12 @@
  *   - "host" pointers are ordinary memory; "_device" entry points take HIP
  *     device pointers on the handle's device and a hipStream_t passed as void*
  *     (NULL = the handle's own stream) and do not synchronise the stream.
+ *     The work a handle enqueues runs in CALL ORDER whichever streams the calls
+ *     name: every entry point first makes its stream wait (an event, no host
+ *     block) for what the handle enqueued before.  So embed_device(stream A) ->
+ *     append_device(stream A) -> search(stream B) scans the appended rows.  One
+ *     exception, on purpose: an append does not wait for searches in flight (it
+ *     only writes rows they do not scan), so ingest and query streams overlap.
  *   - there is NO CPU fallback: without a usable gfx950 device, creation fails
  *     with MI_ERR_NO_DEVICE.
  */
@@ -45,8 +51,9 @@ extern "C" {
 
 #define MI_KNN_NO_ID UINT64_MAX /* id written for missing results (fewer than k rows) */
 
-typedef struct mi_clip mi_clip; /* a loaded vision tower on one GPU */
-typedef struct mi_knn mi_knn;   /* one row-shard of the embedding table on one GPU */
+typedef struct mi_clip mi_clip;         /* a loaded vision (or text) tower on one GPU */
+typedef struct mi_knn mi_knn;           /* one row-shard of the embedding table on one GPU */
+typedef struct mi_pipeline mi_pipeline; /* scan-loop body + query fused on HIP streams (one GPU) */
 
 const char* mi_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
@@ -66,6 +73,15 @@ int mi_device_count(void);
  * 1.16 GB on every scan). */
 int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** out);
 void mi_clip_free(mi_clip* m);
+
+/* Run-time options of a loaded handle (the MI_CLIP_* environment variables only seed them at load;
+ * nothing on the hot path reads the environment):
+ *   "max_batch"  images per internal pass (default 256)
+ *   "parts"      1..4 sub-chunks of a pass run as independent streams (default 2; bf16 tower)
+ *   "full_last"  1 = also compute the rows of the last layer that never reach the output (default 0:
+ *                the pooled output is the CLS row, the result is bit-identical either way)
+ *   "split_tail" 0 = do not cut a short last round of GEMM tiles into quadrant tasks (A/B hook) */
+int mi_clip_set_option(mi_clip* m, const char* key, int value);
 
 /* geometry of a loaded model: out[0..7] = image, patch, tokens, hidden, layers,
  * heads, ff, proj */
@@ -181,6 +197,46 @@ int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint3
  * global top-k under the same ordering.  Host-only. */
 int mi_knn_merge(const uint64_t* idx_in, const float* dist_in, uint32_t lists, uint32_t k,
                  uint64_t* idx, float* dist);
+
+/* ------------------------------------------- fused flow (BASELINE config 4, one GPU) */
+
+/* The body of the scan loop (server/src/clip.rs:107-137: upload -> forward -> readback -> insert)
+ * and the query (server/src/search.rs:70-86) as one pipeline on three HIP streams:
+ *   copy stream    upload of chunk i+1 under the forward of chunk i
+ *   ingest stream  forward; its last kernel writes the embeddings straight into the table's next
+ *                  rows (no readback, no re-upload)
+ *   search stream  the scan of a query and the readback of its k results run under the forward
+ *                  of the following chunk
+ * `model` is an image tower, `table` a shard on the same device with dim == the model's output
+ * width.  Both are borrowed and must outlive the pipeline; they stay usable through their own
+ * entry points (the handles order all work, see Conventions). */
+int mi_pipeline_create(mi_clip* model, mi_knn* table, mi_pipeline** out);
+void mi_pipeline_free(mi_pipeline* p);
+/* Enqueue one chunk: nchw = [n,3,H,W] f32, host memory.  The n embeddings become rows
+ * [size, size+n) of the table; *first_id (may be NULL) = id of the first one.  Returns when the
+ * chunk is queued (at most two chunks are in flight).  With pinned memory (mi_host_alloc) the upload
+ * is asynchronous and the buffer may be refilled once the NEXT mi_pipeline_ingest (or
+ * mi_pipeline_sync) has returned; ordinary memory is staged before the call returns.
+ * n = 0 is a successful no-op, as in mi_clip_embed. */
+int mi_pipeline_ingest(mi_pipeline* p, const float* nchw, size_t n, uint64_t* first_id);
+/* Enqueue one query (q: [dim] f32 host, copied before the call returns) over every row ingested by
+ * the calls made before this one.  idx [k] / dist [k] (host, caller-owned) are filled when
+ * mi_pipeline_sync returns (or when 16 later queries have been enqueued).  Same results and
+ * ordering as mi_knn_search. */
+int mi_pipeline_query(mi_pipeline* p, const float* q, uint32_t k, uint64_t* idx, float* dist);
+/* Wait for everything enqueued and deliver the pending query results. */
+int mi_pipeline_sync(mi_pipeline* p);
+/* Deliver finished queries, oldest first, until at most `leave_pending` are still pending (blocks
+ * for those it delivers; the ingest stream is not waited for).  With leave_pending = 1 a caller gets
+ * the results of query i-1 while query i scans: the per-shard lists a multi-GPU caller all-gathers. */
+int mi_pipeline_drain(mi_pipeline* p, uint32_t leave_pending);
+/* Device time spent in the pipeline's forwards and scans as measured by events on their own streams,
+ * folded in at sync: out = {forwards, total ms of forwards, scans, total ms of scans}; reset != 0 clears. */
+int mi_pipeline_stats(mi_pipeline* p, double out[4], int reset);
+
+/* Page-locked host memory for upload buffers (hipHostMalloc). */
+int mi_host_alloc(size_t bytes, void** out);
+void mi_host_free(void* p);
 
 /* ------------------------------------------------------------ query refinement */
 

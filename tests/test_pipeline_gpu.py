@@ -1,0 +1,177 @@
+"""BASELINE config 4 as written, on a real MI355X and through the C ABI: batch = 256 bf16 ViT-L/14
+embed -> rows appended to the table on the device -> top-k over table + appended rows, fused on HIP
+streams (mi_pipeline_*; reference flow server/src/clip.rs:107-137 + server/src/search.rs:70-86).
+
+Checked against the oracle (oracle/vit_numpy.py, oracle/oracle.c) at the benchmarked shape:
+  images {0, 127, 128, 255} of the batch (both edges of the two 128-image half-chunk streams)
+    bf16 rows in the table : |y - ref| <= 3e-2 * rms(ref)   (the stated bf16 bound, tests/test_vit_gpu.py)
+    fp32 HIP path          : |y - ref| <= 1e-4 * (|ref| + rms(ref))
+  appended rows            : what mi_knn_get_rows returns == what mi_clip_embed returns, bit for bit
+  query                    : ids and distance bits == the oracle on (table rows ++ appended rows)
+and the cross-stream ordering the handles promise (embed_device -> append_device -> search on
+different streams without a host synchronisation in between).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from image_search_amd import synth
+from image_search_amd.clip import PRECISION_BF16, PRECISION_F32, Model
+from image_search_amd.search import EmbeddingTable, PinnedBuffer, Pipeline
+from oracle import vit_numpy
+from oracle.binding import orc_knn
+
+pytestmark = pytest.mark.gpu
+
+SEL = [0, 127, 128, 255]
+N0 = 200_000  # rows already in the table (oracle-sized; the 10 M case is covered by properties in test_knn_gpu.py)
+
+
+def close(out, ref, tol):
+    rms = float(np.sqrt((np.asarray(ref, np.float64) ** 2).mean()))
+    return np.allclose(out, ref, rtol=tol, atol=tol * rms), float(np.abs(out - ref).max() / rms)
+
+
+@pytest.fixture(scope="module")
+def l14_batch(built, tmp_path_factory):
+    cfg = synth.VitConfig.vit_l14()
+    w = synth.vit_weights(cfg, 0)
+    path = str(tmp_path_factory.mktemp("w") / "l14.safetensors")
+    synth.save_safetensors(w, path, {"num_attention_heads": cfg.heads})
+    px = synth.preprocess_rgb8(synth.images_u8(4242, 256, cfg.image))
+    ref = vit_numpy.vit_forward(w, cfg, px[SEL], np.float32)
+    return cfg, path, px, ref
+
+
+def test_config4_batch256_bf16_embed_append_query(l14_batch, orc):
+    cfg, path, px, ref = l14_batch
+    # the fp32 HIP path on the same four images: the parity path at 1e-4
+    m32 = Model.from_file(path, 0, PRECISION_F32)
+    out32 = m32.forward(px[SEL])
+    m32.close()
+    ok, err = close(out32, ref, 1e-4)
+    assert ok, err
+
+    m = Model.from_file(path, 0, PRECISION_BF16)
+    t = EmbeddingTable(768, 0)
+    t.reserve(N0 + 3 * 256)
+    t.insert_synthetic(7, 0, N0)
+    base_rows = synth.corpus_rows(7, 0, N0)
+    pipe = Pipeline(m, t)
+    pin = [PinnedBuffer(px.shape), PinnedBuffer(px.shape)]
+    pin[0].array[:] = px
+    pin[1].array[:40] = px[:40]
+
+    q_rand = synth.corpus_rows(8, 0, 1)[0]
+    q_img = out32[2]                                  # image 128's fp32 embedding: nearest row must be its bf16 twin
+    before = pipe.query(q_rand, 10)                   # enqueued before any ingest: sees the N0 base rows only
+    assert pipe.ingest(pin[0].array) == N0            # chunk 1: 256 images, two half-chunk streams
+    after1 = pipe.query(q_rand, 10)
+    twin = pipe.query(q_img, 10)
+    assert pipe.ingest(pin[1].array[:40]) == N0 + 256  # chunk 2: other buffer, other size
+    assert pipe.ingest(pin[0].array) == N0 + 296      # chunk 3: buffer 0 again (its upload waited for chunk 1's forward)
+    after3 = pipe.query(q_img, 1000)                  # the reference's K
+    assert pipe.ingest(pin[0].array[:0]) == N0 + 552  # n = 0: no-op (clip.rs:112-118)
+    pipe.sync()
+    assert len(t) == N0 + 552
+
+    rows = t.rows(N0, 552)
+    ok, err = close(rows[SEL], ref, 3e-2)             # bf16 bound at the benchmarked shape, vs the oracle
+    assert ok, err
+    direct = m.forward(px)                            # the host entry point: same kernels, same half-chunks
+    assert np.array_equal(rows[:256].view(np.uint32), direct.view(np.uint32))
+    assert np.array_equal(rows[296:552].view(np.uint32), direct.view(np.uint32))
+    assert np.array_equal(rows[256:296].view(np.uint32), m.forward(px[:40]).view(np.uint32))
+    err16 = float(np.abs(rows[SEL] - ref).max() / np.sqrt((ref.astype(np.float64) ** 2).mean()))
+    print(f"config 4, b=256 bf16 vs oracle on images {SEL}: max|err|/rms = {err16:.2e}")
+
+    def same(got, q, table_rows, k):
+        oi, od = orc_knn(orc, q, table_rows, k)
+        assert np.array_equal(got[0], oi), (got[0][:5], oi[:5])
+        assert np.array_equal(got[1].view(np.uint32), od.view(np.uint32))
+
+    same(before, q_rand, base_rows, 10)
+    all1 = np.concatenate([base_rows, rows[:256]])
+    same(after1, q_rand, all1, 10)
+    same(twin, q_img, all1, 10)
+    assert int(twin[0][0]) == N0 + 128 and twin[1][0] < 1e-3
+    same(after3, q_img, np.concatenate([base_rows, rows]), 1000)
+    assert {int(i) for i in after3[0][:2]} == {N0 + 128, N0 + 296 + 128}   # the image was ingested twice
+    pipe.close()
+    for b in pin:
+        b.close()
+    t.close()
+    m.close()
+
+
+def test_handles_order_work_across_streams(l14_batch, orc):
+    """embed_device(stream A) -> append_device(stream A) -> search on ANOTHER stream / the handle's own,
+    no host synchronisation in between: the search must scan the appended rows (the handle
+    keeps an event per kind of work and every entry point waits for it on its own stream)."""
+    import torch
+    cfg, path, px, ref = l14_batch
+    m = Model.from_file(path, 0, PRECISION_BF16)
+    t = EmbeddingTable(768, 0)
+    t.reserve(60_000)
+    t.insert_synthetic(9, 0, 50_000)
+    n = 64
+    d_img = torch.from_numpy(px[:n]).cuda()
+    d_emb = torch.empty((n, 768), dtype=torch.float32, device="cuda")
+    d_q = torch.empty((768,), dtype=torch.float32, device="cuda")
+    d_idx = torch.empty((10,), dtype=torch.int64, device="cuda")
+    d_dist = torch.empty((10,), dtype=torch.float32, device="cuda")
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    m.forward_device(d_img.data_ptr(), n, d_emb.data_ptr(), a.cuda_stream)
+    t.insert_device(d_emb.data_ptr(), n, a.cuda_stream)
+    with torch.cuda.stream(a):
+        d_q.copy_(d_emb[17])                          # the query is one of the rows being appended
+        ev = torch.cuda.Event()
+        ev.record(a)
+    b.wait_event(ev)                                  # the caller orders its OWN buffer (d_q); the table orders itself
+    t.knn_device(d_q.data_ptr(), 1, 10, d_idx.data_ptr(), d_dist.data_ptr(), b.cuda_stream)
+    second = m.forward_device(d_img.data_ptr(), n, d_emb.data_ptr(), b.cuda_stream)  # same workspace, other stream
+    torch.cuda.synchronize()
+    assert second is None
+    emb = d_emb.cpu().numpy()
+    idx = d_idx.cpu().numpy().view(np.uint64)
+    assert int(idx[0]) == 50_000 + 17 and float(d_dist[0]) <= 1e-6
+    rows = t.rows(50_000, n)
+    assert np.array_equal(rows, emb)                  # both forwards give the same bits; the append saw the first
+    oi, od = orc_knn(orc, emb[17], np.concatenate([synth.corpus_rows(9, 0, 50_000), rows]), 10)
+    assert np.array_equal(idx, oi)
+    # the host entry point on the handle's own stream right after an async append on stream a
+    t.insert_device(d_emb.data_ptr(), n, a.cuda_stream)
+    gi, gd = t.knn(emb[5], 3)
+    assert {int(gi[0]), int(gi[1])} == {50_005, 50_000 + n + 5}
+    t.close()
+    m.close()
+
+
+def test_pipeline_argument_errors(built, tmp_path):
+    import ctypes
+    from image_search_amd._lib import MiError, c_vp, lib
+    cfg = synth.VitConfig.tiny()
+    path = str(tmp_path / "tiny.safetensors")
+    synth.save_safetensors(synth.vit_weights(cfg, 1), path, {"num_attention_heads": cfg.heads})
+    m = Model.from_file(path, 0, PRECISION_F32)
+    t768 = EmbeddingTable(768, 0)
+    with pytest.raises(MiError) as e:
+        Pipeline(m, t768)                             # tiny model embeds into 64 dims
+    assert e.value.code == -1
+    t = EmbeddingTable(64, 0)
+    pipe = Pipeline(m, t)
+    px = synth.preprocess_rgb8(synth.images_u8(3, 5, cfg.image))
+    assert pipe.ingest(px) == 0                       # pageable memory works too
+    i, d = pipe.query(np.ones(64, np.float32), 8)
+    pipe.sync()
+    assert np.array_equal(t.rows(0, 5), m.forward(px))
+    assert list(i[5:]) == [0xFFFFFFFFFFFFFFFF] * 3 and np.isinf(d[5:]).all()   # fewer than k rows
+    h = c_vp()
+    assert lib().mi_pipeline_create(None, t._h, ctypes.byref(h)) == -1
+    assert lib().mi_pipeline_query(pipe._h, None, 3, i.ctypes.data, d.ctypes.data) == -1
+    pipe.close()
+    t.close()
+    t768.close()
+    m.close()

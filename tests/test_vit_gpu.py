@@ -296,6 +296,6 @@ def test_cls_only_last_layer_is_bit_identical_to_the_full_one(l14, monkeypatch, 
     px = synth.preprocess_rgb8(synth.images_u8(77, 40, cfg.image))      # 40 images: two half-chunk streams in bf16
     m = Model.from_file(path, 0, prec)
     fast = m.forward(px)
-    monkeypatch.setenv("MI_CLIP_FULL_LAST", "1")
+    m.set_option("full_last", 1)
     full = m.forward(px)
     assert np.array_equal(fast.view(np.uint32), full.view(np.uint32))
