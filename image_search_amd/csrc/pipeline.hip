@@ -14,6 +14,7 @@
 // Ordering is carried by events only (handles.h: mi_clip::order, mi_knn::writes / reads); the host
 // blocks only to keep at most two chunks in flight (so that a caller alternating two upload buffers
 // may refill a buffer as soon as the NEXT ingest call has returned).
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
