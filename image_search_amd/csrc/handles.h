@@ -63,6 +63,9 @@ struct mi_clip {
     hipStream_t stream = nullptr;
     size_t max_batch = 256;
     // options (mi_clip_set_option; the MI_CLIP_* / MI_GEMM_* environment variables only seed them at load)
+    int attn_ver = 2;         // bf16 attention for 64 < S <= 288: 2 = 32-query tiles (attn32_kernels.h), 1 = 16-query tiles
+    bool q_prescaled = false; // log2(e)/8 folded into W_q / b_q at load (attn_ver 2 in the tower)
+    bool attn_shift = false;  // force the shifted (exact maximum) pass of attn32 — test hook
     bool full_last = false;   // compute the dead rows of the last layer too (A/B against the reference graph)
     bool split_tail = true;   // cut a short last round of GEMM tiles into quadrant tasks
     mi::WorkOrder order;          // serialises this handle's enqueued work across caller streams

@@ -165,8 +165,8 @@ struct WaveTopLds {
             }
         }
         thr = buf[k - 1];
-        thr = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(thr >> 32)) << 32) |
-              __builtin_amdgcn_readfirstlane((uint32_t)thr);
+        thr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(thr >> 32)) << 32) |
+              (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)thr);  // (the builtin returns int: no sign extension)
         wave_sync();
         for (int j = KP + lane; j < 2 * KP; j += 64) buf[j] = KEY_MAX;
         cnt = 0;

@@ -16,6 +16,7 @@
 #include "../../include/mi355clip_ops.h"
 #include "preprocess_kernels.h"
 #include "vit_kernels.h"
+#include "attn32_kernels.h"
 
 using namespace mi;
 
@@ -288,6 +289,7 @@ void load_weights(mi_clip* m, const char* path) {
         for (int d = 0; d < D; ++d) std::memcpy(&wp[(size_t)d * m->Kp], &w[(size_t)d * K], (size_t)K * 4);
         m->wpatch = upload_mat(m, wp);
     }
+    m->q_prescaled = m->precision == MI_PRECISION_BF16 && m->attn_ver == 2 && m->S > 64 && m->S <= 288;
     load_layers(m, st, v);
 }
 
@@ -304,8 +306,14 @@ void load_layers(mi_clip* m, SafeTensors& st, const std::string& v) {
         ly.ln2b = upload_f32(m, st.read(p + "layer_norm2.bias", D));
         std::vector<float> wqkv, bqkv;
         for (const char* n : {"q_proj", "k_proj", "v_proj"}) {
-            const auto w = st.read(p + "self_attn." + n + ".weight", (int64_t)D * D);
-            const auto b = st.read(p + "self_attn." + n + ".bias", D);
+            auto w = st.read(p + "self_attn." + n + ".weight", (int64_t)D * D);
+            auto b = st.read(p + "self_attn." + n + ".bias", D);
+            if (m->q_prescaled && n[0] == 'q') {
+                // attn32 takes q in the exp2 domain: log2(e)/8 goes into W_q and b_q here, in fp32, before the
+                // one bf16 rounding of the weights (a constant factor does not change their relative error)
+                for (auto& x : w) x *= ATTN32_C2;
+                for (auto& x : b) x *= ATTN32_C2;
+            }
             wqkv.insert(wqkv.end(), w.begin(), w.end());
             bqkv.insert(bqkv.end(), b.begin(), b.end());
         }
@@ -466,7 +474,28 @@ void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, 
         const int qb = first_tile_only ? 1 : (m->S + 63) / 64;
         const unsigned blocks = (unsigned)(n * m->H * qb);
         hipLaunchKernelGGL(attn_f32_kernel, dim3(blocks), dim3(64), 0, s, (const float*)qkv, (float*)ctx, m->S, m->D, m->H, m->text ? 1 : 0, first_tile_only ? 1 : 0);
+    } else if (m->attn_ver == 2 && !m->text && m->S > 64 && m->S <= 288) {
+#define MI_ATTN32(SP, SC)                                                                                              \
+    {                                                                                                                  \
+        constexpr int LDS = attn32_lds_bytes(SP);                                                                      \
+        static DevOnce once[2];                                                                                        \
+        const int pairs = (int)(n * m->H), grid = std::min(pairs, m->n_cu);                                            \
+        if (m->q_prescaled) {                                                                                          \
+            allow_lds_once(once[1], attn32_bf16_kernel<SP, SC, true>, LDS);                                            \
+            hipLaunchKernelGGL((attn32_bf16_kernel<SP, SC, true>), dim3(grid), dim3(512), LDS, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, pairs, first_tile_only ? 1 : 0, m->attn_shift ? 1 : 0); \
+        } else {                                                                                                       \
+            allow_lds_once(once[0], attn32_bf16_kernel<SP, SC, false>, LDS);                                           \
+            hipLaunchKernelGGL((attn32_bf16_kernel<SP, SC, false>), dim3(grid), dim3(512), LDS, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, pairs, first_tile_only ? 1 : 0, m->attn_shift ? 1 : 0); \
+        }                                                                                                              \
+    }
+        if (m->S == 257) MI_ATTN32(288, 257)       // ViT-L/14, ViT-H/14 @224
+        else if (m->S == 197) MI_ATTN32(224, 197)  // ViT-B/16 @224
+        else if (m->S <= 128) MI_ATTN32(128, 0)
+        else if (m->S <= 224) MI_ATTN32(224, 0)
+        else MI_ATTN32(288, 0)
+#undef MI_ATTN32
     } else {
+        if (m->q_prescaled) fail(MI_ERR_INVALID, "this handle's q weights carry the attn32 scale: attn_ver is fixed at load");
         const unsigned blocks = (unsigned)(n * m->H);
         const int sp = (m->S + 31) / 32 * 32;
 #define MI_ATTN(SP, SC)                                                                                              \
@@ -709,6 +738,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         DeviceGuard g(m->device);
         const std::string k(key);
         if (k == "full_last") m->full_last = value != 0;
+        else if (k == "attn_shift") m->attn_shift = value != 0;
         else if (k == "split_tail") m->split_tail = value != 0;
         else if (k == "max_batch") {
             if (value < 1) fail(MI_ERR_INVALID, "max_batch must be >= 1");
@@ -723,7 +753,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, split_tail, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, max_batch, parts)", key);
     });
 }
 
@@ -746,6 +776,7 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         for (auto& e : m->ev_join) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (const char* e = std::getenv("MI_CLIP_PARTS")) m->parts = std::min(4, std::max(1, std::atoi(e)));
         if (const char* e = std::getenv("MI_CLIP_FULL_LAST")) m->full_last = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MI_CLIP_ATTN")) m->attn_ver = std::atoi(e) == 1 ? 1 : 2;  // fixed at load: decides the q scale
         if (const char* e = std::getenv("MI_GEMM_SPLIT")) m->split_tail = std::atoi(e) != 0;
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -1034,6 +1065,8 @@ int mi_op_attention(int device, int precision, const float* qkv, float* ctx, siz
         Scratch sc;
         mi_clip m;
         m.precision = precision; m.S = s_tok; m.D = d; m.H = heads;
+        if (const char* e = std::getenv("MI_OP_ATTN")) m.attn_ver = std::atoi(e) == 1 ? 1 : 2;   // test hook: which bf16 kernel
+        if (const char* e = std::getenv("MI_OP_ATTN_SHIFT")) m.attn_shift = std::atoi(e) != 0;
         const size_t rows = n_img * s_tok;
         void* dq = sc.up(precision, qkv, rows, 3 * (size_t)d, pad256(rows));
         void* dc = sc.bytes(pad256(rows) * d * 4);

@@ -80,6 +80,8 @@ void mi_clip_free(mi_clip* m);
  *   "parts"      1..4 sub-chunks of a pass run as independent streams (default 2; bf16 tower)
  *   "full_last"  1 = also compute the rows of the last layer that never reach the output (default 0:
  *                the pooled output is the CLS row, the result is bit-identical either way)
+ *   "attn_shift" 1 = always take the shifted (exact row maximum) pass of the bf16 attention (default 0: taken
+ *                only for queries whose softmax numerators leave the exponent range; same result)
  *   "split_tail" 0 = do not cut a short last round of GEMM tiles into quadrant tasks (A/B hook) */
 int mi_clip_set_option(mi_clip* m, const char* key, int value);
 

@@ -112,10 +112,70 @@ def test_attention(built, prec, tol, S):
     qkv[0, 5, :D] *= 6.0  # one sharply peaked query row
     r = bf16_round(qkv) if prec else qkv
     q, k, v = [r[..., i * D:(i + 1) * D].reshape(n, S, H, 64).transpose(0, 2, 1, 3).astype(np.float64) for i in range(3)]
+    if prec and S > 64:
+        # attn32 works in the exp2 domain: a plain q (this hook) is scaled by log2(e)/8 and rounded to bf16 once
+        # more on its way into the MFMA; in the tower that factor sits in W_q / b_q and q is rounded once
+        c2 = np.float32(0.125 * 1.4426950408889634)
+        q = bf16_round(q.astype(np.float32) * c2).astype(np.float64) / np.float64(c2)
     s = q @ k.transpose(0, 1, 3, 2) * 0.125
     e = np.exp(s - s.max(-1, keepdims=True))
     ref = ((e / e.sum(-1, keepdims=True)) @ v).transpose(0, 2, 1, 3).reshape(n, S, D)
     assert np.abs(ops.attention(qkv, H, prec) - ref).max() <= tol * np.abs(ref).max()
+
+
+def _peaked_qkv(S, n, H, beta, gamma, seed):
+    """Query i attends to exactly one key pi(i): keys are random +-1 codes (dims 8..63) plus a common
+    component (dims 0..7 = +1); q_i = beta * code(pi(i)) - gamma * common.  Scores (natural units):
+    (beta * 56 - 8 gamma) / 8 on the chosen key, at most about (beta * 28 - 8 gamma) / 8 elsewhere."""
+    rng = np.random.default_rng(seed)
+    D = 64 * H
+    qkv = np.zeros((n, S, 3 * D), np.float32)
+    pi = np.stack([rng.permutation(S) for _ in range(n * H)]).reshape(n, H, S)
+    for b in range(n):
+        for h in range(H):
+            code = rng.choice([-1.0, 1.0], (S, 64)).astype(np.float32)
+            code[:, :8] = 1.0
+            q = beta * code[pi[b, h]]
+            q[:, :8] = -gamma
+            qkv[b, :, h * 64:(h + 1) * 64] = q
+            qkv[b, :, D + h * 64:D + (h + 1) * 64] = code
+            qkv[b, :, 2 * D + h * 64:2 * D + (h + 1) * 64] = rng.integers(-4, 5, (S, 64))
+    return qkv, pi
+
+
+@pytest.mark.parametrize("S", [65, 100, 128, 197, 224, 257, 288])
+@pytest.mark.parametrize("beta,gamma,why", [(4.0, 0.0, "in range: the unshifted pass"),
+                                            (48.0, 0.0, "numerators overflow: shifted pass"),
+                                            (4.0, 200.0, "every numerator underflows: shifted pass")])
+def test_attention32_one_hot_and_exponent_window(built, S, beta, gamma, why):
+    """attn32 (32-query tiles, no max pass): each query must return exactly its key's V row — any wrong
+    key / column / tile mapping shows — also when the scores leave the window that the unshifted
+    softmax numerators can represent, on both sides."""
+    n, H = 2, 2
+    D = 64 * H
+    qkv, pi = _peaked_qkv(S, n, H, beta, gamma, 11 + S)
+    out = ops.attention(qkv, H, PRECISION_BF16)
+    for b in range(n):
+        for h in range(H):
+            want = qkv[b, pi[b, h], 2 * D + h * 64:2 * D + (h + 1) * 64]
+            got = out[b, :, h * 64:(h + 1) * 64]
+            assert np.abs(got - want).max() <= 2e-3, (why, S, b, h, np.abs(got - want).max())
+
+
+def test_attention32_forced_shift_and_old_kernel_agree(built, monkeypatch):
+    rng = np.random.default_rng(5)
+    n, H, S = 3, 2, 257
+    qkv = rng.standard_normal((n, S, 3 * 64 * H)).astype(np.float32)
+    qkv[1, 9, :64 * H] *= 5.0
+    base = ops.attention(qkv, H, PRECISION_BF16)
+    monkeypatch.setenv("MI_OP_ATTN_SHIFT", "1")
+    shifted = ops.attention(qkv, H, PRECISION_BF16)
+    monkeypatch.delenv("MI_OP_ATTN_SHIFT")
+    monkeypatch.setenv("MI_OP_ATTN", "1")
+    old = ops.attention(qkv, H, PRECISION_BF16)
+    scale = np.abs(base).max()
+    assert np.abs(shifted - base).max() <= 8e-3 * scale     # same mathematics, bf16 numerators rounded at another scale
+    assert np.abs(old - base).max() <= 8e-3 * scale         # the 16-query-tile kernel (q rounded before its scale)
 
 
 @pytest.mark.parametrize("prec,tol", [(PRECISION_F32, 2e-6), (PRECISION_BF16, 5e-3)])
