@@ -50,6 +50,21 @@ SYMBOLS = {
     "mi_knn_search": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     "mi_knn_search_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp]),
     "mi_knn_search_batched_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp]),
+    "mi_knn_sharded_create": (ctypes.c_int, [ctypes.c_uint32, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_uint32,
+                                             ctypes.POINTER(c_vp)]),
+    "mi_knn_sharded_free": (None, [c_vp]),
+    "mi_knn_sharded_info": (ctypes.c_int, [c_vp, c_u64p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
+                                           ctypes.POINTER(ctypes.c_int)]),
+    "mi_knn_sharded_reserve": (ctypes.c_int, [c_vp, ctypes.c_uint64]),
+    "mi_knn_sharded_append": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint64, c_u64p]),
+    "mi_knn_sharded_append_synthetic": (ctypes.c_int, [c_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]),
+    "mi_knn_sharded_get_rows": (ctypes.c_int, [c_vp, ctypes.c_uint64, ctypes.c_uint64, c_vp]),
+    "mi_knn_sharded_search": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
+    "mi_knn_sharded_save": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
+    "mi_knn_sharded_load": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
+    "mi_knn_sharded_place": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32),
+                                            c_u64p]),
+    "mi_knn_sharded_id": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, c_u64p]),
     "mi_knn_merge": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     "mi_pipeline_create": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
     "mi_pipeline_free": (None, [c_vp]),

@@ -13,7 +13,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmi355clip.so")
-SOURCES = ["core.hip", "knn.hip", "vit.hip", "preprocess.hip", "pipeline.hip"]
+SOURCES = ["core.hip", "knn.hip", "vit.hip", "preprocess.hip", "pipeline.hip", "sharded.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable"]
 
@@ -43,7 +43,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
             subprocess.check_call(cmd)
         objs.append(o)
     if force or _stale(LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -45,6 +45,25 @@ inline uint32_t dist_key(float d) {
 
 }  // namespace
 
+namespace mi {
+// global top-k of `lists` candidate lists of k (id, distance) entries under (distance asc, id asc), NaN last
+void merge_lists(const uint64_t* idx_in, const float* dist_in, uint32_t lists, uint32_t k, uint64_t* idx, float* dist) {
+    struct Ent { uint32_t key; uint64_t id; float d; };
+    std::vector<Ent> all;
+    all.reserve((size_t)lists * k);
+    for (size_t i = 0; i < (size_t)lists * k; ++i)
+        if (idx_in[i] != MI_KNN_NO_ID) all.push_back({dist_key(dist_in[i]), idx_in[i], dist_in[i]});
+    const size_t keep = std::min<size_t>(k, all.size());
+    std::partial_sort(all.begin(), all.begin() + keep, all.end(), [](const Ent& a, const Ent& b) {
+        return a.key < b.key || (a.key == b.key && a.id < b.id);
+    });
+    for (uint32_t i = 0; i < k; ++i) {
+        if (i < keep) { idx[i] = all[i].id; dist[i] = all[i].d; }
+        else { idx[i] = MI_KNN_NO_ID; dist[i] = INFINITY; }
+    }
+}
+}  // namespace mi
+
 extern "C" {
 
 const char* mi_last_error(void) { return g_last_error.c_str(); }
@@ -118,19 +137,25 @@ int mi_knn_merge(const uint64_t* idx_in, const float* dist_in, uint32_t lists, u
     return guarded([&] {
         if (k == 0) fail(MI_ERR_INVALID, "k must be >= 1");
         if (!idx || !dist || (lists && (!idx_in || !dist_in))) fail(MI_ERR_INVALID, "null argument");
-        struct Ent { uint32_t key; uint64_t id; float d; };
-        std::vector<Ent> all;
-        all.reserve((size_t)lists * k);
-        for (size_t i = 0; i < (size_t)lists * k; ++i)
-            if (idx_in[i] != MI_KNN_NO_ID) all.push_back({dist_key(dist_in[i]), idx_in[i], dist_in[i]});
-        const size_t keep = std::min<size_t>(k, all.size());
-        std::partial_sort(all.begin(), all.begin() + keep, all.end(), [](const Ent& a, const Ent& b) {
-            return a.key < b.key || (a.key == b.key && a.id < b.id);
-        });
-        for (uint32_t i = 0; i < k; ++i) {
-            if (i < keep) { idx[i] = all[i].id; dist[i] = all[i].d; }
-            else { idx[i] = MI_KNN_NO_ID; dist[i] = INFINITY; }
-        }
+        merge_lists(idx_in, dist_in, lists, k, idx, dist);
+    });
+}
+
+// Block-cyclic placement of mi_knn_sharded (host-only arithmetic, also what the shards' kernels apply):
+// global row -> (shard, local row) and back.
+int mi_knn_sharded_place(uint32_t block_rows, uint32_t n_shards, uint64_t row, uint32_t* shard, uint64_t* local) {
+    return guarded([&] {
+        if (block_rows == 0 || n_shards == 0 || !shard || !local) fail(MI_ERR_INVALID, "bad argument");
+        const uint64_t blk = row / block_rows;
+        *shard = (uint32_t)(blk % n_shards);
+        *local = (blk / n_shards) * block_rows + row % block_rows;
+    });
+}
+
+int mi_knn_sharded_id(uint32_t block_rows, uint32_t n_shards, uint32_t shard, uint64_t local, uint64_t* row) {
+    return guarded([&] {
+        if (block_rows == 0 || n_shards == 0 || shard >= n_shards || !row) fail(MI_ERR_INVALID, "bad argument");
+        *row = ((local / block_rows) * n_shards + shard) * block_rows + local % block_rows;
     });
 }
 

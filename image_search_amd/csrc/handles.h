@@ -77,6 +77,8 @@ struct mi_knn {
     int device = 0;
     uint32_t dim = 0;
     uint64_t base = 0, rows = 0, cap = 0;
+    // a shard of a block-cyclic table (mi_knn_sharded): ids = base + ((local / block) * n + rank) * block + local % block
+    uint32_t cyc_block = 0, cyc_n = 0, cyc_rank = 0;
     float* table = nullptr;
     hipStream_t stream = nullptr;
     int n_cu = 0;

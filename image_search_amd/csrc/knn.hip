@@ -5,7 +5,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <unistd.h>
+
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -17,6 +20,8 @@ using namespace mi;
 namespace {
 
 constexpr int MAX_BATCH_Q = 8;
+
+IdMap id_map(const mi_knn* t) { return IdMap{t->base, t->cyc_block, t->cyc_n, t->cyc_rank}; }
 
 void ensure(mi_knn* t, void** p, size_t* have, size_t want, size_t elem) {
     if (*have >= want) return;
@@ -130,7 +135,7 @@ void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint
 void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
     if (t->rows == 0) {  // nothing stored: k "none" entries
         hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s,
-                           (const uint64_t*)nullptr, k, t->base, d_idx, d_dist, (size_t)0, (size_t)0);
+                           (const uint64_t*)nullptr, k, id_map(t), d_idx, d_dist, (size_t)0, (size_t)0);
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -144,7 +149,7 @@ void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float*
         else if (kp <= 256) one_pass<WaveTopLds<256>>(t, d_q, kp, lo, out, s);
         else one_pass<WaveTopLds<1024>>(t, d_q, kp, lo, out, s);
     }
-    hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, t->base,
+    hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, id_map(t),
                        d_idx, d_dist, (size_t)0, (size_t)0);
     HIP_CHECK(hipGetLastError());
 }
@@ -182,7 +187,7 @@ void search_batched(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64
         launch_merge<WaveTopReg>(t->d_cand, lists, k, lpb, t->d_tmp, nq, cstride, (size_t)mid * k, s);
         launch_merge<WaveTopReg>(t->d_tmp, mid, k, mid, t->d_keys, nq, (size_t)mid * k, k, s);
     }
-    hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, nq), dim3(256), 0, s, t->d_keys, k, t->base,
+    hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, nq), dim3(256), 0, s, t->d_keys, k, id_map(t),
                        d_idx, d_dist, (size_t)k, (size_t)k);
     HIP_CHECK(hipGetLastError());
 }
@@ -363,22 +368,33 @@ int mi_knn_save(mi_knn* t, const char* path) {
         std::lock_guard<std::mutex> l(t->mu);
         DeviceGuard g(t->device);
         own_stream(t);
-        File f(path, "wb");
-        if (!f.f) fail(MI_ERR_IO, "cannot create %s", path);
-        KnnFileHeader h{};
-        std::memcpy(h.magic, "MIKNNv01", 8);
-        h.dim = t->dim; h.rows = t->rows; h.base = t->base;
-        if (std::fwrite(&h, sizeof h, 1, f.f) != 1) fail(MI_ERR_IO, "write to %s failed", path);
-        const size_t total = (size_t)t->rows * t->dim * sizeof(float);
-        if (total == 0) return;
-        PinnedBuf buf(std::min(total, IO_CHUNK));
-        t->writes.begin(t->stream);
-        for (size_t off = 0; off < total; off += IO_CHUNK) {
-            const size_t n = std::min(IO_CHUNK, total - off);
-            HIP_CHECK(hipMemcpyAsync(buf.p, (const char*)t->table + off, n, hipMemcpyDeviceToHost, t->stream));
-            HIP_CHECK(hipStreamSynchronize(t->stream));
-            if (std::fwrite(buf.p, 1, n, f.f) != n) fail(MI_ERR_IO, "write to %s failed", path);
+        // crash-safe: everything goes to `<path>.tmp`, is flushed and fsync'ed, and only then renamed over
+        // `path` — a full disk or a crash leaves the previous file, never a truncated one that reports success
+        const std::string tmp = std::string(path) + ".tmp";
+        {
+            File f(tmp.c_str(), "wb");
+            if (!f.f) fail(MI_ERR_IO, "cannot create %s", tmp.c_str());
+            KnnFileHeader h{};
+            std::memcpy(h.magic, "MIKNNv01", 8);
+            h.dim = t->dim; h.rows = t->rows; h.base = t->base;
+            if (std::fwrite(&h, sizeof h, 1, f.f) != 1) fail(MI_ERR_IO, "write to %s failed", tmp.c_str());
+            const size_t total = (size_t)t->rows * t->dim * sizeof(float);
+            if (total) {
+                PinnedBuf buf(std::min(total, IO_CHUNK));
+                t->writes.begin(t->stream);
+                for (size_t off = 0; off < total; off += IO_CHUNK) {
+                    const size_t n = std::min(IO_CHUNK, total - off);
+                    HIP_CHECK(hipMemcpyAsync(buf.p, (const char*)t->table + off, n, hipMemcpyDeviceToHost, t->stream));
+                    HIP_CHECK(hipStreamSynchronize(t->stream));
+                    if (std::fwrite(buf.p, 1, n, f.f) != n) fail(MI_ERR_IO, "write to %s failed (disk full?)", tmp.c_str());
+                }
+            }
+            if (std::fflush(f.f) != 0 || fsync(fileno(f.f)) != 0) fail(MI_ERR_IO, "flush of %s failed", tmp.c_str());
+            FILE* fp = f.f;
+            f.f = nullptr;
+            if (std::fclose(fp) != 0) fail(MI_ERR_IO, "close of %s failed", tmp.c_str());
         }
+        if (std::rename(tmp.c_str(), path) != 0) fail(MI_ERR_IO, "cannot rename %s to %s", tmp.c_str(), path);
     });
 }
 
@@ -396,6 +412,9 @@ int mi_knn_load(mi_knn* t, const char* path) {
             fail(MI_ERR_IO, "%s is not a MIKNNv01 shard file", path);
         if (h.dim != t->dim) fail(MI_ERR_INVALID, "%s holds dim %u rows, the table has dim %u", path, h.dim, t->dim);
         if (t->rows == 0) t->base = h.base;  // an empty table takes the shard's id range
+        else if (h.base != t->base + t->rows)
+            fail(MI_ERR_INVALID, "%s starts at id %llu; the table (base %llu, %llu rows) would renumber its rows", path,
+                 (unsigned long long)h.base, (unsigned long long)t->base, (unsigned long long)t->rows);
         const size_t total = (size_t)h.rows * t->dim * sizeof(float);
         if (total == 0) return;
         grow(t, t->rows + h.rows);

@@ -469,8 +469,17 @@ __global__ __launch_bounds__(256) void knn_merge_block_kernel(const uint64_t* __
     for (uint32_t j = tid; j < k; j += 256) out[(size_t)blockIdx.x * k + j] = buf[j];
 }
 
+// Row ids of a shard.  Plain: id = base + local ordinal.  Block-cyclic (a shard of mi_knn_sharded: global row r lives in
+// block r / B, blocks are dealt round-robin to the n shards): id = base + ((local / B) * n + rank) * B + local % B —
+// monotone in the local ordinal, so "(distance asc, local asc)" inside a shard IS "(distance asc, id asc)".
+struct IdMap { uint64_t base; uint32_t block, n, rank; };
+__host__ __device__ inline uint64_t id_of_local(const IdMap& m, uint64_t local) {
+    if (m.n <= 1 || m.block == 0) return m.base + local;
+    return m.base + ((local / m.block) * m.n + m.rank) * m.block + local % m.block;
+}
+
 // keys (ascending, KEY_MAX = none) -> (id, distance); one thread per result slot.
-__global__ void knn_finalize_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint64_t base,
+__global__ void knn_finalize_kernel(const uint64_t* __restrict__ keys, uint32_t n, IdMap map,
                                     uint64_t* __restrict__ idx, float* __restrict__ dist,
                                     size_t key_stride, size_t out_stride) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -482,7 +491,7 @@ __global__ void knn_finalize_kernel(const uint64_t* __restrict__ keys, uint32_t 
         oi[j] = MI_KNN_NO_ID;
         od[j] = __uint_as_float(0x7F800000u);
     } else {
-        oi[j] = base + (uint32_t)key;
+        oi[j] = id_of_local(map, (uint32_t)key);
         od[j] = u32_to_dist((uint32_t)(key >> 32));
     }
 }

@@ -207,6 +207,67 @@ def merge_candidates(idx_lists: np.ndarray, dist_lists: np.ndarray, k: int):
     return idx, dist
 
 
+class ShardedTable:
+    """`image.embedding` row-sharded over the GPUs of one node inside ONE process (mi_knn_sharded_*): the
+    reference's one-handle, one-search-at-a-time shape (main.rs:30-35, search.rs:26) for BASELINE config 5.
+    Same `insert` / `knn` surface as EmbeddingTable; ids are global insertion ordinals."""
+
+    TRANSPORTS = {0: "single shard", 1: "host gather", 2: "rccl all-gather"}
+
+    def __init__(self, dim: int = 768, devices: Sequence[int] = (0,), block_rows: int = 0):
+        self._h = c_vp()
+        self.dim = dim
+        devs = (ctypes.c_int * len(devices))(*devices)
+        check(lib().mi_knn_sharded_create(dim, devs, len(devices), block_rows, ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mi_knn_sharded_free(self._h)
+            self._h = c_vp()
+
+    __del__ = close
+
+    def info(self):
+        rows, n, blk, tr = ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_int()
+        check(lib().mi_knn_sharded_info(self._h, ctypes.byref(rows), ctypes.byref(n), ctypes.byref(blk), ctypes.byref(tr)))
+        return {"rows": rows.value, "shards": n.value, "block_rows": blk.value, "transport": self.TRANSPORTS[tr.value]}
+
+    def __len__(self) -> int:
+        return self.info()["rows"]
+
+    def reserve(self, rows: int):
+        check(lib().mi_knn_sharded_reserve(self._h, rows))
+
+    def insert(self, embeddings: np.ndarray) -> int:
+        e = _f32(embeddings).reshape(-1, self.dim)
+        first = ctypes.c_uint64()
+        check(lib().mi_knn_sharded_append(self._h, e.ctypes.data, e.shape[0], ctypes.byref(first)))
+        return first.value
+
+    def insert_synthetic(self, seed: int, first_row: int, n: int):
+        check(lib().mi_knn_sharded_append_synthetic(self._h, seed, first_row, n))
+
+    def rows(self, first: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.dim), np.float32)
+        check(lib().mi_knn_sharded_get_rows(self._h, first, n, out.ctypes.data))
+        return out
+
+    def knn(self, reference: np.ndarray, k: int = K_REFERENCE):
+        q = _f32(reference)
+        single = q.ndim == 1
+        q = q.reshape(-1, self.dim)
+        idx = np.empty((q.shape[0], k), np.uint64)
+        dist = np.empty((q.shape[0], k), np.float32)
+        check(lib().mi_knn_sharded_search(self._h, q.ctypes.data, q.shape[0], k, idx.ctypes.data, dist.ctypes.data))
+        return (idx[0], dist[0]) if single else (idx, dist)
+
+    def save(self, prefix: str):
+        check(lib().mi_knn_sharded_save(self._h, prefix.encode()))
+
+    def load(self, prefix: str):
+        check(lib().mi_knn_sharded_load(self._h, prefix.encode()))
+
+
 def shard_bounds(n_rows: int, world: int, rank: int):
     """Contiguous row split: rank r owns [r*N/W, (r+1)*N/W)."""
     return (n_rows * rank) // world, (n_rows * (rank + 1)) // world

@@ -54,6 +54,7 @@ extern "C" {
 typedef struct mi_clip mi_clip;         /* a loaded vision (or text) tower on one GPU */
 typedef struct mi_knn mi_knn;           /* one row-shard of the embedding table on one GPU */
 typedef struct mi_pipeline mi_pipeline; /* scan-loop body + query fused on HIP streams (one GPU) */
+typedef struct mi_knn_sharded mi_knn_sharded; /* the table row-sharded over several GPUs, one process */
 
 const char* mi_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
@@ -169,9 +170,10 @@ int mi_knn_append_synthetic(mi_knn* t, uint64_t seed, uint64_t first_row, uint64
 int mi_knn_get_rows(mi_knn* t, uint64_t first, uint64_t n, float* out);
 
 /* Persistence of a shard (what the database's storage does for `image.embedding`,
- * server/src/clip.rs:125-137): mi_knn_save writes {32-byte header, rows*dim f32} to `path`;
- * mi_knn_load appends a file's rows to the table (an empty table also takes the file's id base).
- * Streamed in 64 MiB pieces: no host copy of the table on either side. */
+ * server/src/clip.rs:125-137): mi_knn_save writes {32-byte header, rows*dim f32} to `path` (through
+ * `path`.tmp + fsync + rename: a crash or a full disk leaves the previous file); mi_knn_load appends a
+ * file's rows to the table (an empty table takes the file's id base; a non-empty one accepts only the
+ * file that continues its ids).  Streamed in 64 MiB pieces: no host copy of the table on either side. */
 int mi_knn_save(mi_knn* t, const char* path);
 int mi_knn_load(mi_knn* t, const char* path);
 
@@ -193,6 +195,35 @@ int mi_knn_search_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, u
  * results identical to nq calls of mi_knn_search_device with nq = 1. */
 int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx,
                                  float* d_dist, void* stream);
+
+/* ---------------------------------------------- Seam B over several GPUs, ONE process */
+
+/* The reference server is one process holding one database handle (server/src/main.rs:30-35), one search at
+ * a time (server/src/search.rs:26).  mi_knn_sharded keeps that shape for a table larger than one GPU:
+ * `n_dev` shards on `devices[]` (BASELINE config 5: 8 x 10 M rows) behind one handle.
+ *   rows    block-cyclic: global row r (= its id, the insertion ordinal) is in block r / block_rows, blocks are
+ *           dealt round-robin to the shards (block_rows = 0 -> 4096; a multiple of 64).  Appends keep ids global.
+ *   search  the query goes to every device, the shards scan concurrently on their own streams, the per-shard
+ *           top-k lists (12 k bytes per shard and query) are all-gathered — RCCL ncclAllGather over xGMI between
+ *           distinct devices; through pinned host memory when a device is listed twice or librccl is absent —
+ *           and merged once.  Result = what ONE mi_knn holding every row returns, bit for bit.
+ * A device may be listed more than once (several shards on one GPU: how a one-GPU box tests n > 1). */
+int mi_knn_sharded_create(uint32_t dim, const int* devices, int n_dev, uint32_t block_rows, mi_knn_sharded** out);
+void mi_knn_sharded_free(mi_knn_sharded* t);
+/* any of the outputs may be NULL; transport: 0 = single shard, 1 = host gather, 2 = RCCL all-gather */
+int mi_knn_sharded_info(const mi_knn_sharded* t, uint64_t* rows, uint32_t* n_shards, uint32_t* block_rows, int* transport);
+int mi_knn_sharded_reserve(mi_knn_sharded* t, uint64_t rows);
+int mi_knn_sharded_append(mi_knn_sharded* t, const float* rows, uint64_t n, uint64_t* first_id /* may be NULL */);
+int mi_knn_sharded_append_synthetic(mi_knn_sharded* t, uint64_t seed, uint64_t first_row, uint64_t n);
+int mi_knn_sharded_get_rows(mi_knn_sharded* t, uint64_t first, uint64_t n, float* out);
+int mi_knn_sharded_search(mi_knn_sharded* t, const float* q, uint32_t nq, uint32_t k, uint64_t* idx, float* dist);
+/* `<prefix>.<s>of<n>.miknn` per shard + `<prefix>.shards`; load needs an empty table and re-deals the blocks when the
+ * shard count or block size differ from the saved ones (rebalancing through the host). */
+int mi_knn_sharded_save(mi_knn_sharded* t, const char* prefix);
+int mi_knn_sharded_load(mi_knn_sharded* t, const char* prefix);
+/* the placement arithmetic by itself (host-only): global row <-> (shard, local row) */
+int mi_knn_sharded_place(uint32_t block_rows, uint32_t n_shards, uint64_t row, uint32_t* shard, uint64_t* local);
+int mi_knn_sharded_id(uint32_t block_rows, uint32_t n_shards, uint32_t shard, uint64_t local, uint64_t* row);
 
 /* Deterministic merge of `lists` candidate lists of k (id, dist) entries each —
  * what every rank holds after the all-gather of per-shard results — into the

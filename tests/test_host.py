@@ -115,6 +115,43 @@ def test_merge_matches_oracle_and_single_table(mi, orc):
     assert mi_i.tolist() == [5, 2 ** 64 - 1] and np.isinf(mi_d[1])
 
 
+@pytest.mark.parametrize("n_shards,block", [(2, 64), (3, 128), (8, 64), (5, 4096)])
+def test_block_cyclic_shards_merge_to_the_single_table_result(mi, orc, n_shards, block):
+    """mi_knn_sharded on the CPU side: the placement arithmetic (global row <-> shard, local row), per-shard
+    top-k with ids mapped back (here by the oracle: the HIP scan is checked against it on the GPU), and the
+    one merge — the result must be the single-table top-k bit for bit, ties and missing results included."""
+    import ctypes
+    from image_search_amd import synth
+    from image_search_amd.search import merge_candidates
+    from oracle.binding import orc_knn
+    n_rows, k = 3000, 40
+    rows = synth.corpus_rows(21, 0, n_rows)
+    rows[100] = rows[2900]                      # exact ties across shards: broken by the GLOBAL id
+    rows[1500] = 0.0                            # a zero row: NaN distance, sorts last
+    q = synth.corpus_rows(22, 0, 1)[0]
+    shard_rows = [[] for _ in range(n_shards)]
+    sh, loc, back = ctypes.c_uint32(), ctypes.c_uint64(), ctypes.c_uint64()
+    for r in range(n_rows):
+        assert mi.mi_knn_sharded_place(block, n_shards, r, ctypes.byref(sh), ctypes.byref(loc)) == 0
+        assert loc.value == len(shard_rows[sh.value])            # appending in order keeps every shard contiguous
+        shard_rows[sh.value].append(r)
+        assert mi.mi_knn_sharded_id(block, n_shards, sh.value, loc.value, ctypes.byref(back)) == 0 and back.value == r
+    li = np.full((n_shards, k), 0xFFFFFFFFFFFFFFFF, np.uint64)
+    ld = np.full((n_shards, k), np.inf, np.float32)
+    for s_, ids in enumerate(shard_rows):
+        if not ids:
+            continue
+        i, d = orc_knn(orc, q, rows[ids], k)
+        ok = i != np.uint64(0xFFFFFFFFFFFFFFFF)
+        li[s_, ok] = np.asarray(ids, np.uint64)[i[ok].astype(np.int64)]   # local ordinal -> global id (monotone)
+        ld[s_] = d
+    gi, gd = merge_candidates(li, ld, k)
+    fi, fd = orc_knn(orc, q, rows, k)
+    assert np.array_equal(gi, fi) and np.array_equal(gd.view(np.uint32), fd.view(np.uint32))
+    assert mi.mi_knn_sharded_place(0, 2, 5, ctypes.byref(sh), ctypes.byref(loc)) == -1
+    assert mi.mi_knn_sharded_id(64, 2, 2, 5, ctypes.byref(back)) == -1
+
+
 def test_shard_bounds_partition():
     for n in (0, 1, 7, 80_000_000):
         for w in (1, 2, 3, 8):

@@ -1,12 +1,17 @@
-"""Aggregate a rocprofv3 --pmc counter_collection csv: mean counter value per kernel name."""
-import csv, glob, sys, collections
-f = sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True))[-1]
+"""Per-kernel means of rocprofv3 --pmc counter passes: python tools/pmc_table.py DIR [DIR ...] [--kernel SUBSTR]
+Each DIR holds one pass (rocprofv3 --pmc ... --kernel-trace -d DIR --output-format csv)."""
+import collections, csv, glob, sys
+
+dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
+sub = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--kernel=")), "")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in csv.DictReader(open(f)):
-    acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-pat = sys.argv[2] if len(sys.argv) > 2 else ""
+for d in dirs:
+    for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if sub in k:
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
-    if pat and pat not in k: continue
     print(k)
     for c, v in sorted(cs.items()):
-        print(f"    {c:28s} mean {sum(v)/len(v):16.1f}  n={len(v)}")
+        print(f"  {c:34s} {sum(v) / len(v):16.1f}   (n={len(v)})")
