@@ -16,6 +16,7 @@ from ._lib import c_vp, check, lib
 
 PRECISION_F32 = 0   # parity path (<= 1e-4 relative vs the fp32 CPU oracle)
 PRECISION_BF16 = 1  # throughput path (bf16 MFMA operands, fp32 accumulate/residual)
+PRECISION_BF16_SPLIT = 2  # bf16 with LayerNorm outputs split into hi + lo halves (outlier channels), ~1.5x the tower time
 
 EXTENSIONS = ("jpg", "jpeg", "png", "gif", "bmp", "webp", "tiff")
 

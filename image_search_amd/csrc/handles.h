@@ -63,6 +63,7 @@ struct mi_clip {
     hipStream_t stream = nullptr;
     size_t max_batch = 256;
     // options (mi_clip_set_option; the MI_CLIP_* / MI_GEMM_* environment variables only seed them at load)
+    bool split_ln = false;    // MI_PRECISION_BF16_SPLIT: LayerNorm outputs as hi + lo bf16 pairs, q/k/v and fc1 run over K = 2D
     int attn_ver = 2;         // bf16 attention for 64 < S <= 288: 2 = 32-query tiles (attn32_kernels.h), 1 = 16-query tiles
     bool q_prescaled = false; // log2(e)/8 folded into W_q / b_q at load (attn_ver 2 in the tower)
     bool attn_shift = false;  // force the shifted (exact maximum) pass of attn32 — test hook

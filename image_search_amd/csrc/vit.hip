@@ -197,10 +197,15 @@ float* upload_f32(mi_clip* m, const std::vector<float>& h) {
     return d;
 }
 
-// GEMM operand in the model's precision
-void* upload_mat(mi_clip* m, const std::vector<float>& h) {
+// GEMM operand in the model's precision; dup_k > 0: every row of k = dup_k values is stored twice, [W | W]
+// (the operand of a GEMM whose activations arrive as hi | lo halves, MI_PRECISION_BF16_SPLIT)
+void* upload_mat(mi_clip* m, const std::vector<float>& h, size_t dup_k = 0) {
     if (m->precision == MI_PRECISION_F32) return upload_f32(m, h);
-    std::vector<uint16_t> b(h.size());
+    std::vector<uint16_t> b(h.size() * (dup_k ? 2 : 1));
+    if (dup_k) {
+        for (size_t r = 0; r < h.size() / dup_k; ++r)
+            for (size_t c = 0; c < dup_k; ++c) b[r * 2 * dup_k + c] = b[r * 2 * dup_k + dup_k + c] = f32_to_bf16_host(h[r * dup_k + c]);
+    } else
     for (size_t i = 0; i < h.size(); ++i) b[i] = f32_to_bf16_host(h[i]);
     uint16_t* d = dalloc<uint16_t>(m, b.size(), m->allocs);
     HIP_CHECK(hipMemcpy(d, b.data(), b.size() * 2, hipMemcpyHostToDevice));
@@ -317,11 +322,11 @@ void load_layers(mi_clip* m, SafeTensors& st, const std::string& v) {
             wqkv.insert(wqkv.end(), w.begin(), w.end());
             bqkv.insert(bqkv.end(), b.begin(), b.end());
         }
-        ly.wqkv = upload_mat(m, wqkv);
+        ly.wqkv = upload_mat(m, wqkv, m->split_ln ? (size_t)D : 0);
         ly.bqkv = upload_f32(m, bqkv);
         ly.wo = upload_mat(m, st.read(p + "self_attn.out_proj.weight", (int64_t)D * D));
         ly.bo = upload_f32(m, st.read(p + "self_attn.out_proj.bias", D));
-        ly.w1 = upload_mat(m, st.read(p + "mlp.fc1.weight", (int64_t)FF * D));
+        ly.w1 = upload_mat(m, st.read(p + "mlp.fc1.weight", (int64_t)FF * D), m->split_ln ? (size_t)D : 0);
         ly.b1 = upload_f32(m, st.read(p + "mlp.fc1.bias", FF));
         ly.w2 = upload_mat(m, st.read(p + "mlp.fc2.weight", (int64_t)D * FF));
         ly.b2 = upload_f32(m, st.read(p + "mlp.fc2.bias", D));
@@ -361,14 +366,14 @@ void ensure_workspace(mi_clip* m, size_t n) {
         m->act[a].col = bytes(Pa * m->Kp * es);
         m->act[a].patch = (float*)bytes(Pa * m->D * 4);
         m->act[a].x = (float*)bytes(Ma * m->D * 4);
-        m->act[a].y = bytes(Ma * m->D * es);
+        m->act[a].y = bytes(Ma * m->D * es * (m->split_ln ? 2 : 1));
         m->act[a].qkv = bytes(Ma * 3 * m->D * es);
         m->act[a].h = bytes(Ma * m->FF * es);
         m->act[a].delta = (bf16_t*)bytes(Ma * m->D * 2);
         m->act[a].delta2 = (bf16_t*)bytes(Ma * m->D * 2);
         const size_t Ca = pad256(na);
         m->act[a].c_ctx = bytes(Ca * m->D * es);
-        m->act[a].c_y = bytes(Ca * m->D * es);
+        m->act[a].c_y = bytes(Ca * m->D * es * (m->split_ln ? 2 : 1));
         m->act[a].c_h = bytes(Ca * m->FF * es);
         m->act[a].c_x = (float*)bytes(Ca * m->D * 4);
         m->act[a].c_d1 = (bf16_t*)bytes(Ca * m->D * 2);
@@ -455,15 +460,17 @@ void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out
         default: fail(MI_ERR_UNSUPPORTED, "hidden size %d has no LayerNorm instantiation", D); \
     }
 
+// y pitch: D, or 2D with the lo halves behind the hi halves (split_ln)
 void layer_norm(mi_clip* m, float* x, const bf16_t* d1, const bf16_t* d2, bool write_back, void* y, const float* w,
                 const float* b, size_t rows, hipStream_t s) {
     const unsigned blocks = (unsigned)((rows + 3) / 4);
+    const int split = m->split_ln ? 1 : 0, y_ld = m->D * (1 + split);
     if (m->precision == MI_PRECISION_F32) {
-        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<float, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (float*)y, w, b, (int)rows, m->eps));
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<float, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (float*)y, w, b, (int)rows, m->eps, y_ld, 0));
     } else if (write_back) {
-        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps));
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, y_ld, split));
     } else {
-        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, false>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps));
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, false>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, y_ld, split));
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -527,6 +534,7 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     const int D = m->D, S = m->S, FF = m->FF;
     const size_t px = (size_t)m->image * m->image * 3;
     const bool deferred = m->precision == MI_PRECISION_BF16;
+    const int Kln = m->split_ln ? 2 * D : D;  // K of the GEMMs fed by a LayerNorm (q/k/v, fc1): hi | lo halves when split
     const int parts = (deferred && m->parts > 1 && n >= 32) ? m->parts : 1;
     struct Part { size_t n, M, P; const float* img; float* out; hipStream_t s; mi_clip::Act* a; const bf16_t *p1, *p2; } pt[4];
     for (size_t p = 0, first = 0; p < (size_t)parts; ++p) {
@@ -574,16 +582,16 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
             Part& q = pt[p];
             layer_norm(m, q.a->x, q.p1, q.p2, true, q.a->y, ly.ln1w, ly.ln1b, q.M, q.s);
             if (!last) {
-                gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, D, 3 * D, q.s);
+                gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, Kln, 3 * D, q.s);
             } else {
                 // keys and values of every token, queries of the CLS rows only (the other rows of the
                 // leading query tile keep whatever the buffer held: their context rows are never read)
                 const size_t es = esize(m);
-                gemm<EPI_BIAS>(m, q.a->y, (const char*)ly.wqkv + (size_t)D * D * es, ly.bqkv + D, (char*)q.a->qkv + (size_t)D * es, q.M, 2 * D, D, 3 * D, q.s);
+                gemm<EPI_BIAS>(m, q.a->y, (const char*)ly.wqkv + (size_t)D * Kln * es, ly.bqkv + D, (char*)q.a->qkv + (size_t)D * es, q.M, 2 * D, Kln, 3 * D, q.s);
                 const unsigned gb = (unsigned)std::min<size_t>((q.n * (size_t)D / 4 + 255) / 256, 4096);
-                if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, q.s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_y, (int)q.n, (size_t)S, D);
+                if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, q.s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_y, (int)q.n, (size_t)S, Kln);
                 else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb), dim3(256), 0, q.s, (const float*)q.a->y, (float*)q.a->c_y, (int)q.n, (size_t)S, D);
-                gemm<EPI_BIAS>(m, q.a->c_y, ly.wqkv, ly.bqkv, q.a->c_ctx, q.n, D, D, D, q.s);
+                gemm<EPI_BIAS>(m, q.a->c_y, ly.wqkv, ly.bqkv, q.a->c_ctx, q.n, D, Kln, D, q.s);
                 if (deferred) hipLaunchKernelGGL((scatter_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, q.s, (const bf16_t*)q.a->c_ctx, (bf16_t*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)3 * D);
                 else hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3(gb), dim3(256), 0, q.s, (const float*)q.a->c_ctx, (float*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)3 * D);
                 HIP_CHECK(hipGetLastError());
@@ -601,12 +609,12 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
                 if (deferred) {
                     gemm<EPI_BIAS>(m, q.a->c_ctx, ly.wo, ly.bo, q.a->c_d1, q.n, D, D, D, q.s);
                     layer_norm(m, q.a->c_x, q.a->c_d1, nullptr, false, q.a->c_y, ly.ln2w, ly.ln2b, q.n, q.s);
-                    gemm<EPI_BIAS_QGELU>(m, q.a->c_y, ly.w1, ly.b1, q.a->c_h, q.n, FF, D, FF, q.s);
+                    gemm<EPI_BIAS_QGELU>(m, q.a->c_y, ly.w1, ly.b1, q.a->c_h, q.n, FF, Kln, FF, q.s);
                     gemm<EPI_BIAS>(m, q.a->c_h, ly.w2, ly.b2, q.a->c_d2, q.n, D, FF, D, q.s);
                 } else {
                     gemm<EPI_BIAS_RESID>(m, q.a->c_ctx, ly.wo, ly.bo, q.a->c_x, q.n, D, D, D, q.s);
                     layer_norm(m, q.a->c_x, nullptr, nullptr, true, q.a->c_y, ly.ln2w, ly.ln2b, q.n, q.s);
-                    gemm<EPI_BIAS_QGELU>(m, q.a->c_y, ly.w1, ly.b1, q.a->c_h, q.n, FF, D, FF, q.s);
+                    gemm<EPI_BIAS_QGELU>(m, q.a->c_y, ly.w1, ly.b1, q.a->c_h, q.n, FF, Kln, FF, q.s);
                     gemm<EPI_BIAS_RESID>(m, q.a->c_h, ly.w2, ly.b2, q.a->c_x, q.n, D, FF, D, q.s);
                 }
                 MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, q.s, q.a->c_x, deferred ? q.a->c_d1 : (const bf16_t*)nullptr, deferred ? q.a->c_d2 : (const bf16_t*)nullptr, m->post_w, m->post_b, m->proj, q.out, (int)q.n, 1, m->E, m->eps, (const int*)nullptr));
@@ -619,13 +627,13 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
             if (deferred) {
                 gemm<EPI_BIAS>(m, q.a->y, ly.wo, ly.bo, q.a->delta, q.M, D, D, D, q.s);
                 layer_norm(m, q.a->x, q.a->delta, nullptr, false, q.a->y, ly.ln2w, ly.ln2b, q.M, q.s);
-                gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, D, FF, q.s);
+                gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, Kln, FF, q.s);
                 gemm<EPI_BIAS>(m, q.a->h, ly.w2, ly.b2, q.a->delta2, q.M, D, FF, D, q.s);
                 q.p1 = q.a->delta; q.p2 = q.a->delta2;
             } else {
                 gemm<EPI_BIAS_RESID>(m, q.a->y, ly.wo, ly.bo, q.a->x, q.M, D, D, D, q.s);
                 layer_norm(m, q.a->x, nullptr, nullptr, true, q.a->y, ly.ln2w, ly.ln2b, q.M, q.s);
-                gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, D, FF, q.s);
+                gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, Kln, FF, q.s);
                 gemm<EPI_BIAS_RESID>(m, q.a->h, ly.w2, ly.b2, q.a->x, q.M, D, FF, D, q.s);
             }
         }
@@ -763,12 +771,13 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         if (!out) fail(MI_ERR_INVALID, "out is null");
         *out = nullptr;
         if (!weights_path) fail(MI_ERR_INVALID, "weights_path is null");
-        if (precision != MI_PRECISION_F32 && precision != MI_PRECISION_BF16)
-            fail(MI_ERR_INVALID, "precision %d: use MI_PRECISION_F32 (0) or MI_PRECISION_BF16 (1)", precision);
+        if (precision != MI_PRECISION_F32 && precision != MI_PRECISION_BF16 && precision != MI_PRECISION_BF16_SPLIT)
+            fail(MI_ERR_INVALID, "precision %d: use MI_PRECISION_F32 (0), MI_PRECISION_BF16 (1) or MI_PRECISION_BF16_SPLIT (2)", precision);
         DeviceGuard g(device);
         m = new mi_clip();
         m->device = device;
-        m->precision = precision;
+        m->precision = precision == MI_PRECISION_BF16_SPLIT ? MI_PRECISION_BF16 : precision;
+        m->split_ln = precision == MI_PRECISION_BF16_SPLIT;
         if (const char* e = std::getenv("MI_CLIP_MAX_BATCH")) m->max_batch = std::max(1, std::atoi(e));
         // aux streams are created on first use: HIP multiplexes streams onto 4 hardware queues
         // (GPU_MAX_HW_QUEUES), and two streams that share a queue do not overlap

@@ -214,11 +214,14 @@ struct LnRow {
 //   d1, d2 nullable.  WRITE_BACK: x[row] <- the sum (once per layer, in LN1); LN2 only reads
 //   x + d1 — it is added again, in the same order, by the next LN1, which saves one fp32 write of
 //   the residual stream per layer.
+//   y_ld: row pitch of y in elements.  split (bf16 only, MI_PRECISION_BF16_SPLIT): y[row][D + c] receives the part of
+//   the normalised value that bf16 rounding dropped, lo = bf16(v - float(bf16(v))): the GEMM that follows runs
+//   over K = 2D against [W | W] and sees the activations to ~16 significant bits.
 template <typename T, int VEC, int NT, bool WRITE_BACK>
 __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const bf16_t* __restrict__ d1,
                                                  const bf16_t* __restrict__ d2, T* __restrict__ y,
                                                  const float* __restrict__ w, const float* __restrict__ b, int rows,
-                                                 float eps) {
+                                                 float eps, int y_ld, int split) {
     constexpr int D = 64 * VEC * NT;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -229,7 +232,14 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const bf
     if (d2) r.add_bf16(d2 + (size_t)row * D, lane);
     if (WRITE_BACK && (d1 || d2)) r.store(x + (size_t)row * D, lane);
     r.normalize(w, b, eps, lane);
-    r.store(y + (size_t)row * D, lane);
+    r.store(y + (size_t)row * y_ld, lane);
+    if constexpr (sizeof(T) == 2) {
+        if (split) {
+#pragma unroll
+            for (int j = 0; j < VEC * NT; ++j) r.v[j] -= bf2f(f2bf(r.v[j]));
+            r.store(y + (size_t)row * y_ld + D, lane);
+        }
+    }
 }
 
 // token assembly + pre-LN (modeling_clip.py:198-218, :641-651):

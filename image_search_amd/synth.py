@@ -80,6 +80,54 @@ def photo_u8(seed: int, height: int, width: int) -> np.ndarray:
     return np.clip(base + noise, 0, 255).astype(np.uint8)
 
 
+def scenes_u8(seed: int, n: int, size: int = 224) -> np.ndarray:
+    """n seeded images that DIFFER from one another the way photos do (uniform noise images all look alike
+    to a ViT: every patch has the same statistics): per image a random palette, 2-4 oriented sinusoidal
+    gratings of random frequency and phase, a soft blob and mild pixel noise.  [n,size,size,3] u8."""
+    out = np.empty((n, size, size, 3), np.uint8)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / np.float32(size)
+    for i in range(n):
+        p = gen_f32(seed * 7919 + 13, i * 64, 64, 1.0).astype(np.float32)      # this image's parameters
+        img = np.zeros((size, size, 3), np.float32)
+        base = 128 + 60 * p[0:3]
+        for g in range(2 + int(abs(p[3]) * 1.5) % 3):
+            fx, fy, ph = 2 + 14 * abs(p[4 + 4 * g]), 2 + 14 * abs(p[5 + 4 * g]), 6.28 * p[6 + 4 * g]
+            img += (np.sin(6.2832 * (fx * xx + fy * yy) + ph)[..., None] * (40 * p[20 + 3 * g:23 + 3 * g])).astype(np.float32)
+        cx, cy, rad = 0.5 + 0.3 * p[40], 0.5 + 0.3 * p[41], 0.08 + 0.1 * abs(p[42])
+        blob = np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * rad * rad))
+        img += blob[..., None] * (90 * p[43:46])
+        with np.errstate(over="ignore"):
+            key = _mix64(np.array([seed * 1000003 + i], dtype=np.uint64) + _GOLDEN)[0]
+            k = np.arange(size * size * 3, dtype=np.uint64)
+            noise = ((_mix64(k + key) >> np.uint64(59)).astype(np.float32) - 16.0).reshape(size, size, 3)
+        out[i] = np.clip(base + img + noise, 0, 255).astype(np.uint8)
+    return out
+
+
+def plant_outlier_channels(weights: dict, dims=(7, 301, 666, 900), factor: float = 50.0, compensate: bool = False) -> dict:
+    """Trained CLIP ViT-L towers carry a few channels two orders of magnitude above the rest; random-init
+    weights do not.  Scales the LayerNorm gains AND biases of `dims` in every layer_norm1/2 by `factor`, so that
+    the GEMM inputs see such channels.  compensate=True divides the matching input columns of q/k/v and fc1 by
+    the same factor: the function is unchanged (up to rounding), only the intermediate magnitudes differ —
+    separates "bf16 cannot represent outliers" (it can: a float keeps its relative precision) from "the planted
+    channels change the function" (they make the softmax sharply peaked).  Returns a new dict."""
+    out = dict(weights)
+    d = list(dims)
+    f = np.float32(factor)
+    for name, w in weights.items():
+        if name.endswith("layer_norm1.weight") or name.endswith("layer_norm2.weight") or \
+                name.endswith("layer_norm1.bias") or name.endswith("layer_norm2.bias"):
+            w = w.copy()
+            w[d] *= f
+            out[name] = w
+        elif compensate and (name.endswith("q_proj.weight") or name.endswith("k_proj.weight") or
+                             name.endswith("v_proj.weight") or name.endswith("fc1.weight")):
+            w = w.copy()
+            w[:, d] /= f
+            out[name] = w
+    return out
+
+
 def preprocess_rgb8(hwc: np.ndarray) -> np.ndarray:
     """image_prepare_resnet's arithmetic, server/src/clip.rs:158-172: p/255, minus
     ImageNet mean, divided by ImageNet std, planar CHW f32 (fp32 ops throughout)."""

@@ -48,6 +48,8 @@ extern "C" {
 
 #define MI_PRECISION_F32 0  /* fp32 in / fp32 accumulate: the parity path (<= 1e-4 rel) */
 #define MI_PRECISION_BF16 1 /* bf16 MFMA operands, fp32 accumulate + fp32 residual stream */
+#define MI_PRECISION_BF16_SPLIT 2 /* as BF16, but every LayerNorm output feeds its GEMM as a hi + lo bf16 pair (K = 2D
+                                   * against [W | W]): for towers whose LayerNorm outputs carry outlier channels */
 
 #define MI_KNN_NO_ID UINT64_MAX /* id written for missing results (fewer than k rows) */
 

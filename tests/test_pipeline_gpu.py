@@ -175,3 +175,56 @@ def test_pipeline_argument_errors(built, tmp_path):
     t.close()
     t768.close()
     m.close()
+
+
+def test_bf16_retrieval_agrees_with_fp32_and_outlier_channels_do_not_matter(built, tmp_path):
+    """What the bf16 tower costs downstream (profiles/r02_bf16_acceptance.json holds the 4096-image run of
+    tools/bf16_acceptance.py): the same structured images indexed from fp32 and from bf16 embeddings, held-out
+    queries embedded in the index's own precision.  Pinned here on 1024 + 50 images:
+      * seeded weights: top-10 / top-100 id sets agree >= 99 %, the nearest image is the same;
+      * channels 50x above the rest planted WITHOUT changing the function (LayerNorm gain x50, the matching
+        q/k/v/fc1 input columns /50): nothing changes — a float keeps its relative precision at any magnitude;
+      * the same channels planted so that the function changes (attention logits ~10x: sharply peaked softmax):
+        the bf16 error doubles; MI_PRECISION_BF16_SPLIT (LayerNorm outputs as hi + lo halves) recovers part of it."""
+    from image_search_amd.clip import PRECISION_BF16_SPLIT
+    cfg = synth.VitConfig.vit_l14()
+    w = synth.vit_weights(cfg, 0)
+    px_i = synth.preprocess_rgb8(synth.scenes_u8(5, 1024, cfg.image))
+    px_q = synth.preprocess_rgb8(synth.scenes_u8(6, 50, cfg.image))
+
+    def run(weights, prec):
+        path = str(tmp_path / "w.safetensors")
+        synth.save_safetensors(weights, path, {"num_attention_heads": cfg.heads})
+        m = Model.from_file(path, 0, prec)
+        out = [np.concatenate([m.forward(x[i:i + 256]) for i in range(0, len(x), 256)]) for x in (px_i, px_q)]
+        m.close()
+        return out
+
+    def agreement(ref, got, ks=(1, 10, 100)):
+        res = {}
+        tabs = []
+        for e, q in (ref, got):
+            t = EmbeddingTable(768, 0)
+            t.insert(e)
+            tabs.append(t.knn(q, max(ks))[0])
+            t.close()
+        for k in ks:
+            res[k] = float(np.mean([len(set(tabs[0][u, :k].tolist()) & set(tabs[1][u, :k].tolist())) / k for u in range(len(ref[1]))]))
+        rms = float(np.sqrt((ref[0].astype(np.float64) ** 2).mean()))
+        return float(np.abs(got[0] - ref[0]).max() / rms), res
+
+    report = {}
+    for name, weights in (("generated", w), ("outliers, function preserved", synth.plant_outlier_channels(w, compensate=True)),
+                          ("outliers, function changed", synth.plant_outlier_channels(w))):
+        ref = run(weights, PRECISION_F32)
+        report[name] = {"bf16": agreement(ref, run(weights, PRECISION_BF16))}
+        if name != "generated":
+            report[name]["bf16_split"] = agreement(ref, run(weights, PRECISION_BF16_SPLIT))
+    print(report)
+    for name in ("generated", "outliers, function preserved"):
+        err, agree = report[name]["bf16"]
+        assert err <= 3e-2, (name, err)
+        assert agree[1] >= 0.98 and agree[10] >= 0.99 and agree[100] >= 0.99, (name, agree)
+    err16, _ = report["outliers, function changed"]["bf16"]
+    errsp, agree_sp = report["outliers, function changed"]["bf16_split"]
+    assert err16 <= 6e-2 and errsp <= err16 * 1.05 and agree_sp[10] >= 0.97, report["outliers, function changed"]
