@@ -91,6 +91,10 @@ struct mi_knn {
     uint64_t* d_idx = nullptr;
     float* d_dist = nullptr;
     size_t cand_keys = 0, tmp_keys = 0, keys_cap = 0, idx_cap = 0, dist_cap = 0;
+    bool select_path = true;       // 64 < k <= 4096 by radix select over all keys (MI_KNN_SELECT=0: the per-wave LDS lists)
+    uint32_t* d_keys32 = nullptr;  // one distance key per row (selection path, 64 < k <= 4096)
+    uint32_t* d_sel = nullptr;     // 6 x 2048 histogram bins + the collect counter
+    size_t keys32_cap = 0, sel_cap = 0;
     // Order across caller streams.  `writes`: the last append (a search must see every row counted in
     // `rows`).  `reads`: the last search (searches share the workspace above, and a reallocation of the
     // table must wait for them).  An append only ever writes rows beyond `rows`, so it does not wait

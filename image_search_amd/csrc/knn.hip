@@ -132,6 +132,36 @@ void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint
     }
 }
 
+// 64 < k <= 4096: every row's distance key, then the k smallest (distance, id) keys by radix select (knn_kernels.h)
+void select_pass(mi_knn* t, const float* d_q, uint32_t k, uint64_t* keys_out, hipStream_t s) {
+    const uint64_t n_tiles = (t->rows + 63) / 64;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 4, (n_tiles + 3) / 4);
+    blocks = std::max(blocks, 1u);
+    ensure(t, (void**)&t->d_keys32, &t->keys32_cap, (size_t)t->cap, sizeof(uint32_t));
+    ensure(t, (void**)&t->d_sel, &t->sel_cap, (size_t)6 * SEL_BINS + 64, sizeof(uint32_t));
+    ensure(t, (void**)&t->d_cand, &t->cand_keys, (size_t)4096, sizeof(uint64_t));
+    HIP_CHECK(hipMemsetAsync(t->d_sel, 0, ((size_t)6 * SEL_BINS + 64) * sizeof(uint32_t), s));
+    switch (t->dim / 64) {
+#define MI_CASE(NCH)                                                                                          \
+    case NCH:                                                                                                 \
+        hipLaunchKernelGGL((knn_scan_kernel<NCH, WaveTopReg, 1>), dim3(blocks), dim3(256), 0, s, t->table, t->rows, d_q, k, \
+                           (const uint64_t*)nullptr, (uint64_t*)nullptr, t->d_keys32);                        \
+        break;
+        MI_CASE(1) MI_CASE(2) MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16)
+#undef MI_CASE
+        default: fail(MI_ERR_UNSUPPORTED, "dim %u: built for dim/64 in {1,2,4,8,12,16}", t->dim);
+    }
+    HIP_CHECK(hipGetLastError());
+    const uint32_t hb = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 8, (t->rows + 255) / 256);
+    uint32_t* count = t->d_sel + 6 * SEL_BINS;
+    SelState* states = reinterpret_cast<SelState*>(t->d_sel + 6 * SEL_BINS + 4);  // 6 states of 24 bytes behind the counter
+    for (int p = 0; p < 6; ++p)
+        hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, p, t->d_sel, states);
+    hipLaunchKernelGGL(knn_select_collect_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, t->d_sel, states, t->d_cand, count);
+    hipLaunchKernelGGL(knn_select_sort_kernel, dim3(1), dim3(1024), 0, s, t->d_cand, count, k, keys_out);
+    HIP_CHECK(hipGetLastError());
+}
+
 void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
     if (t->rows == 0) {  // nothing stored: k "none" entries
         hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s,
@@ -140,7 +170,14 @@ void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float*
         return;
     }
     const uint32_t passes = (k + 1023) / 1024;
-    ensure(t, (void**)&t->d_keys, &t->keys_cap, (size_t)passes * 1024, sizeof(uint64_t));
+    ensure(t, (void**)&t->d_keys, &t->keys_cap, (size_t)std::max<uint32_t>(passes * 1024, 4096), sizeof(uint64_t));
+    if (k > 64 && k <= 4096 && t->select_path) {
+        select_pass(t, d_q, k, t->d_keys, s);
+        hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, id_map(t),
+                           d_idx, d_dist, (size_t)0, (size_t)0);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     for (uint32_t p = 0; p < passes; ++p) {
         const uint32_t kp = std::min(1024u, k - p * 1024);
         uint64_t* out = t->d_keys + (size_t)p * 1024;
@@ -222,6 +259,7 @@ int mi_knn_create(uint32_t dim, int device, mi_knn** out) {
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         t->n_cu = prop.multiProcessorCount;
         HIP_CHECK(hipMalloc((void**)&t->d_q, (size_t)16 * dim * sizeof(float)));
+        if (const char* e = std::getenv("MI_KNN_SELECT")) t->select_path = std::atoi(e) != 0;  // A/B hook, read at creation
         *out = t;
     });
 }
@@ -234,7 +272,7 @@ void mi_knn_free(mi_knn* t) {
     t->reads.destroy();
     if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
     for (void* p : {(void*)t->table, (void*)t->d_q, (void*)t->d_cand, (void*)t->d_tmp, (void*)t->d_keys,
-                    (void*)t->d_idx, (void*)t->d_dist})
+                    (void*)t->d_idx, (void*)t->d_dist, (void*)t->d_keys32, (void*)t->d_sel})
         if (p) (void)hipFree(p);
     delete t;
 }

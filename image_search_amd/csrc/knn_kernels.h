@@ -210,11 +210,15 @@ struct RowAcc {
 // grid: any number of 256-thread blocks; wave w of the grid takes tiles w, w+W, ...
 // cand: [gridDim.x*4][k] keys out.  lo_ptr (nullable): keys <= *lo_ptr are skipped
 // (used when k > 1024 is served in several passes).
-template <int NCH, class Top>
+// KEYS = 0: per-wave top-k lists into cand.  KEYS = 1: no selection here, every row's 32-bit distance key goes to
+// all_keys (one 256-byte store per tile: +2 % on the scan; holding the keys of 8 tiles in LDS and flushing them
+// together was measured at +17 %) for knn_select_* below.
+template <int NCH, class Top, int KEYS = 0>
 __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const float* __restrict__ table, uint64_t n_rows,
                                                        const float* __restrict__ q, uint32_t k,
                                                        const uint64_t* __restrict__ lo_ptr,
-                                                       uint64_t* __restrict__ cand) {
+                                                       uint64_t* __restrict__ cand,
+                                                       uint32_t* __restrict__ all_keys = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int DIM = NCH * 64;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -266,12 +270,167 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const float* __restric
         }
         const uint64_t r = (tile << 6) + lane;
         const float dist = 1.0f - mydot / (sq * sqrtf(myxx));
+        if constexpr (KEYS == 1) {
+            if (r < n_rows) all_keys[r] = dist_to_u32(dist);
+            continue;
+        }
         uint64_t key = r < n_rows ? make_key(dist, (uint32_t)r) : KEY_MAX;
         if (use_lo && key <= lo) key = KEY_MAX;
         top.offer(key);
     }
+    if constexpr (KEYS != 0) return;
     top.finish();
     top.store(cand + (size_t)wave * k);
+}
+
+// ---- selection over ALL distance keys (64 < k <= 4096: the reference's K = 1000) ------------------------------
+// The per-wave lists above stop paying when k approaches the rows a wave sees (1 M rows, k = 1000: 2048 lists of
+// 488 rows each, everything "passes", the tree merge of 2048 x 1000 keys cost as much as the scan).  Instead the
+// scan writes one 32-bit distance key per row (4 bytes per 3 KiB row read: +0.13 % traffic) and the k smallest
+// 64-bit keys (distance << 32 | row: unique, so there is exactly one answer and ties break by id) are found by a
+// most-significant-digit radix select: 6 digits (11, 11, 10 bits of the distance, then of the row id), one
+// histogram pass over the keys per digit; the passes over the row digits return at once unless the k-th distance
+// is shared by more rows than fit (exact duplicates).  Then one pass collects the keys <= the k-th and one block
+// sorts them.  Independent of the insertion order and of k.
+constexpr int SEL_BINS = 2048;
+__device__ __forceinline__ int sel_shift(int p) { return p == 0 ? 53 : p == 1 ? 42 : p == 2 ? 32 : p == 3 ? 21 : p == 4 ? 10 : 0; }
+__device__ __forceinline__ uint32_t sel_mask(int p) { return (p == 2 || p == 5) ? 0x3FFu : 0x7FFu; }
+
+// The pick of pass p-1 is made by EVERY block of the kernel that runs pass p (all reach the same answer from the
+// same complete histogram): state after p-1 passes comes from `states[p-2]` (written by the blocks of the previous
+// kernel, all with the same value), the histogram of pass p-1 is scanned by the block (256 threads x 8 bins,
+// Hillis-Steele over the partials), and the new state goes to states[p-1].
+// prefix = the digits chosen so far (as the high bits of the key), k_rem = rank of the wanted key inside that prefix
+// group (1-based), done = the group holds exactly k_rem keys (take them all), fixed = digits chosen.
+struct SelState { uint64_t prefix; uint32_t k_rem; int done; int fixed; };
+static_assert(sizeof(SelState) == 24, "layout of the state words in d_sel");
+__device__ inline SelState sel_advance(const uint32_t* __restrict__ hist, SelState* __restrict__ states, int n_pass, uint32_t k,
+                                       uint64_t n_rows) {
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t s_bin, s_rem, s_cnt;
+    SelState st{0ull, k, 0, 0};
+    if (n_rows < k) { st.done = 1; return st; }  // fewer rows than k: everything is taken
+    if (n_pass == 0) return st;
+    if (n_pass >= 2) st = states[n_pass - 2];
+    if (st.done) {  // decided earlier: hand the verdict on (the next kernel reads states[n_pass - 1])
+        if (threadIdx.x == 0) states[n_pass - 1] = st;
+        return st;
+    }
+    const int p = n_pass - 1;
+    const uint32_t* h = hist + p * SEL_BINS;
+    uint32_t mine[8], loc = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mine[j] = h[threadIdx.x * 8 + j]; loc += mine[j]; }
+    part[threadIdx.x] = loc;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {  // inclusive scan of the 256 partials
+        const uint32_t v = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const uint32_t incl = part[threadIdx.x], excl = incl - loc;
+    if (excl < st.k_rem && st.k_rem <= incl) {  // exactly one thread: the wanted rank falls into its 8 bins
+        uint32_t acc = excl;
+        int j = 0;
+        while (j < 7 && acc + mine[j] < st.k_rem) acc += mine[j++];
+        s_bin = threadIdx.x * 8 + j; s_rem = st.k_rem - acc; s_cnt = mine[j];
+    }
+    __syncthreads();
+    st.prefix |= (uint64_t)s_bin << sel_shift(p);
+    st.k_rem = s_rem;
+    st.done = s_cnt == s_rem;  // the whole group is wanted: its lower digits do not matter
+    st.fixed = p + 1;
+    if (threadIdx.x == 0) states[p] = st;  // every block writes the same words
+    __syncthreads();
+    return st;
+}
+
+// pass `p`: histogram of digit p over the keys that match the prefix chosen so far
+__global__ __launch_bounds__(256) void knn_select_hist_kernel(const uint32_t* __restrict__ keys, uint64_t n_rows, uint32_t k,
+                                                              int p, uint32_t* __restrict__ hist, SelState* __restrict__ states) {
+    __shared__ uint32_t lh[SEL_BINS];
+    const SelState st = sel_advance(hist, states, p, k, n_rows);
+    if (st.done) return;
+    for (int j = threadIdx.x; j < SEL_BINS; j += 256) lh[j] = 0;
+    __syncthreads();
+    const int sh = sel_shift(p);
+    const uint32_t mk = sel_mask(p);
+    const uint64_t hi_mask = p == 0 ? 0ull : ~0ull << sel_shift(p - 1);
+    auto count_key = [&](uint64_t key, bool live) {
+        const bool hit = live && (key & hi_mask) == st.prefix;
+        const uint32_t bin = (uint32_t)(key >> sh) & mk;
+        // cosine distances of a corpus crowd into a handful of leading digits: when every hit of the wave falls into
+        // one bin (always, in pass 0) one lane adds the count instead of 64 lanes hammering one LDS word
+        const unsigned long long hits = __ballot(hit);
+        if (hits == 0ull) return;
+        const uint32_t first = __builtin_amdgcn_readfirstlane(__shfl((int)bin, __ffsll((long long)hits) - 1, 64));
+        if (__ballot(hit && bin != first) == 0ull) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(&lh[first], (uint32_t)__popcll(hits));
+        } else if (hit) {
+            atomicAdd(&lh[bin], 1u);
+        }
+    };
+    // 4 consecutive rows per thread (one 16-byte load); the table's row count is a multiple of nothing: tail by hand
+    const uint64_t n4 = n_rows >> 2;
+    for (uint64_t q4 = (uint64_t)blockIdx.x * 256 + threadIdx.x; q4 < ((n4 + 63) & ~63ull); q4 += (uint64_t)gridDim.x * 256) {
+        const bool live = q4 < n4;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (live) v = reinterpret_cast<const uint4*>(keys)[q4];
+        const uint64_t r0 = q4 << 2;
+        count_key(((uint64_t)v.x << 32) | (uint32_t)(r0 + 0), live);
+        count_key(((uint64_t)v.y << 32) | (uint32_t)(r0 + 1), live);
+        count_key(((uint64_t)v.z << 32) | (uint32_t)(r0 + 2), live);
+        count_key(((uint64_t)v.w << 32) | (uint32_t)(r0 + 3), live);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {  // the last n_rows % 4 rows
+        const uint64_t r = (n4 << 2) + threadIdx.x;
+        const bool live = threadIdx.x < (n_rows & 3);
+        count_key(live ? (((uint64_t)keys[r] << 32) | (uint32_t)r) : 0ull, live);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < SEL_BINS; j += 256)
+        if (lh[j]) atomicAdd(&hist[p * SEL_BINS + j], lh[j]);
+}
+
+// every key <= the k-th smallest goes to out (unordered); count = how many (== min(k, n_rows))
+__global__ __launch_bounds__(256) void knn_select_collect_kernel(const uint32_t* __restrict__ keys, uint64_t n_rows, uint32_t k,
+                                                                 const uint32_t* __restrict__ hist, SelState* __restrict__ states,
+                                                                 uint64_t* __restrict__ out, uint32_t* __restrict__ count) {
+    const SelState st = sel_advance(hist, states, 6, k, n_rows);
+    // the k-th key: the chosen digits; when a whole group was taken its lower digits are free (all ones);
+    // fewer rows than k: every key
+    uint64_t T = KEY_MAX;
+    if (n_rows >= k) T = st.fixed == 6 ? st.prefix : (st.prefix | ((1ull << sel_shift(st.fixed - 1)) - 1ull));
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * 256) {
+        const uint64_t key = ((uint64_t)keys[r] << 32) | (uint32_t)r;
+        if (key <= T) {
+            const uint32_t at = atomicAdd(count, 1u);
+            if (at < k) out[at] = key;
+        }
+    }
+}
+
+// one block: the (<= 4096) collected keys ascending into out[0, k), KEY_MAX behind them
+__global__ __launch_bounds__(1024) void knn_select_sort_kernel(const uint64_t* __restrict__ in, const uint32_t* __restrict__ count,
+                                                               uint32_t k, uint64_t* __restrict__ out) {
+    __shared__ uint64_t buf[4096];
+    const uint32_t n = min(*count, k);
+    int np = 64;
+    while ((uint32_t)np < k) np <<= 1;  // the power of two that holds k (<= 4096)
+    for (int j = threadIdx.x; j < np; j += 1024) buf[j] = (uint32_t)j < n ? in[j] : KEY_MAX;
+    __syncthreads();
+    for (int kk = 2; kk <= np; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int p = threadIdx.x; p < np / 2; p += 1024) {
+                const int a = ((p & ~(j - 1)) << 1) | (p & (j - 1)), b = a | j;
+                const uint64_t x = buf[a], y = buf[b];
+                const bool up = (a & kk) == 0;
+                if ((x > y) == up) { buf[a] = y; buf[b] = x; }
+            }
+            __syncthreads();
+        }
+    for (uint32_t j = threadIdx.x; j < k; j += 1024) out[j] = buf[j];
 }
 
 // Q queries in one pass over the table (throughput variant).  Same per-row

@@ -46,7 +46,7 @@ for k in (10, 64, 100, 1000):
     for it in range(iters): t.knn_device(dq[it % 16].data_ptr(), 1, k, di.data_ptr(), dd.data_ptr(), s)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    print(f"k={k}: {ms:.3f} ms/query  {NP*3072/ms/1e9:.1f} GB/s  ({NP*3072/ms/1e9/8000*100:.1f}% of 8 TB/s)  qps {1000/ms:.1f}")
+    print(f"k={k}: {ms:.3f} ms/query  {NP*3072/ms/1e6:.1f} GB/s  ({NP*3072/ms/1e6/8000*100:.1f}% of 8 TB/s)  qps {1000/ms:.1f}")
 # batched: nq queries per table pass
 for nq in (2, 4, 8):
     k = 10
