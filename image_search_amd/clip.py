@@ -133,9 +133,9 @@ class TextModel:
         (_, _, self.positions, self.hidden, self.layers, self.heads, self.ff, self.proj) = list(info)
 
     @classmethod
-    def from_file(cls, path: str, device: int = 0) -> "TextModel":
+    def from_file(cls, path: str, device: int = 0, precision: int = PRECISION_F32) -> "TextModel":
         h = c_vp()
-        check(lib().mi_clip_load_text(path.encode(), device, PRECISION_F32, ctypes.byref(h)))
+        check(lib().mi_clip_load_text(path.encode(), device, precision, ctypes.byref(h)))
         return cls(h)
 
     def close(self):

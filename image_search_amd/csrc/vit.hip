@@ -509,13 +509,14 @@ void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, 
     {                                                                                                                \
         static DevOnce once;                                                                                         \
         allow_lds_once(once, attn_bf16_kernel<SP, SC>, SP * 256);                                                    \
-        hipLaunchKernelGGL((attn_bf16_kernel<SP, SC>), dim3(blocks), dim3(256), SP * 256, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, first_tile_only ? 1 : 0); \
+        hipLaunchKernelGGL((attn_bf16_kernel<SP, SC>), dim3(blocks), dim3(256), SP * 256, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, first_tile_only ? 1 : 0, m->text ? 1 : 0); \
     }
         if (m->S == 257) MI_ATTN(288, 257)       // ViT-L/14, ViT-H/14 @224
         else if (m->S == 197) MI_ATTN(224, 197)  // ViT-B/16 @224
         else if (m->S == 50) MI_ATTN(64, 50)     // ViT-B/32 @224
         else if (sp <= 32) MI_ATTN(32, 0)
         else if (sp <= 64) MI_ATTN(64, 0)
+        else if (sp <= 96) MI_ATTN(96, 0)        // the text tower's 77 positions
         else if (sp <= 224) MI_ATTN(224, 0)
         else if (sp <= 288) MI_ATTN(288, 0)
         else fail(MI_ERR_UNSUPPORTED, "bf16 attention is built for up to 288 tokens (got %d)", m->S);
@@ -675,10 +676,15 @@ void ensure_text_workspace(mi_clip* m, size_t n) {
         m->ws.push_back(p);
         return p;
     };
+    const size_t es = esize(m);
     m->act[0].x = (float*)bytes(Ma * m->D * 4);
-    m->act[0].y = bytes(Ma * m->D * 4);
-    m->act[0].qkv = bytes(Ma * 3 * m->D * 4);
-    m->act[0].h = bytes(Ma * m->FF * 4);
+    m->act[0].y = bytes(Ma * m->D * es);
+    m->act[0].qkv = bytes(Ma * 3 * m->D * es);
+    m->act[0].h = bytes(Ma * m->FF * es);
+    if (m->precision == MI_PRECISION_BF16) {
+        m->act[0].delta = (bf16_t*)bytes(Ma * m->D * 2);
+        m->act[0].delta2 = (bf16_t*)bytes(Ma * m->D * 2);
+    }
     m->d_ids = (int*)bytes(Ma * sizeof(int));
     m->d_rows = (int*)bytes(n * sizeof(int));
     m->d_out = (float*)bytes(n * m->E * 4);
@@ -695,16 +701,26 @@ void forward_text(mi_clip* m, size_t n, hipStream_t s) {
                        m->d_ids, m->tok, m->pos, a.x, M, S, D);
     hipLaunchKernelGGL(text_eos_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, m->d_ids, (int)n, S, m->d_rows);
     HIP_CHECK(hipGetLastError());
-    for (const Layer& ly : m->layers) {  // the vision tower's fp32 block with the causal attention
-        layer_norm(m, a.x, nullptr, nullptr, true, a.y, ly.ln1w, ly.ln1b, M, s);
+    const bool deferred = m->precision == MI_PRECISION_BF16;
+    const bf16_t *p1 = nullptr, *p2 = nullptr;  // bf16: the residual adds of the previous layer, applied by its LayerNorms
+    for (const Layer& ly : m->layers) {  // the vision tower's block with the causal attention
+        layer_norm(m, a.x, p1, p2, true, a.y, ly.ln1w, ly.ln1b, M, s);
         gemm<EPI_BIAS>(m, a.y, ly.wqkv, ly.bqkv, a.qkv, M, 3 * D, D, 3 * D, s);
         attention(m, a.qkv, a.y, n, s);
-        gemm<EPI_BIAS_RESID>(m, a.y, ly.wo, ly.bo, a.x, M, D, D, D, s);
-        layer_norm(m, a.x, nullptr, nullptr, true, a.y, ly.ln2w, ly.ln2b, M, s);
-        gemm<EPI_BIAS_QGELU>(m, a.y, ly.w1, ly.b1, a.h, M, FF, D, FF, s);
-        gemm<EPI_BIAS_RESID>(m, a.h, ly.w2, ly.b2, a.x, M, D, FF, D, s);
+        if (deferred) {
+            gemm<EPI_BIAS>(m, a.y, ly.wo, ly.bo, a.delta, M, D, D, D, s);
+            layer_norm(m, a.x, a.delta, nullptr, false, a.y, ly.ln2w, ly.ln2b, M, s);
+            gemm<EPI_BIAS_QGELU>(m, a.y, ly.w1, ly.b1, a.h, M, FF, D, FF, s);
+            gemm<EPI_BIAS>(m, a.h, ly.w2, ly.b2, a.delta2, M, D, FF, D, s);
+            p1 = a.delta; p2 = a.delta2;
+        } else {
+            gemm<EPI_BIAS_RESID>(m, a.y, ly.wo, ly.bo, a.x, M, D, D, D, s);
+            layer_norm(m, a.x, nullptr, nullptr, true, a.y, ly.ln2w, ly.ln2b, M, s);
+            gemm<EPI_BIAS_QGELU>(m, a.y, ly.w1, ly.b1, a.h, M, FF, D, FF, s);
+            gemm<EPI_BIAS_RESID>(m, a.h, ly.w2, ly.b2, a.x, M, D, FF, D, s);
+        }
     }
-    MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((n + 7) / 8), 16), dim3(256), 0, s, a.x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, m->post_w, m->post_b, m->proj, m->d_out, (int)n, S, m->E, m->eps, (const int*)m->d_rows));
+    MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((n + 7) / 8), 16), dim3(256), 0, s, a.x, p1, p2, m->post_w, m->post_b, m->proj, m->d_out, (int)n, S, m->E, m->eps, (const int*)m->d_rows));
     HIP_CHECK(hipGetLastError());
 }
 
@@ -805,7 +821,8 @@ int mi_clip_load_text(const char* weights_path, int device, int precision, mi_cl
         if (!out) fail(MI_ERR_INVALID, "out is null");
         *out = nullptr;
         if (!weights_path) fail(MI_ERR_INVALID, "weights_path is null");
-        if (precision != MI_PRECISION_F32) fail(MI_ERR_UNSUPPORTED, "the text tower runs in MI_PRECISION_F32 only");
+        if (precision != MI_PRECISION_F32 && precision != MI_PRECISION_BF16)
+            fail(MI_ERR_UNSUPPORTED, "the text tower runs in MI_PRECISION_F32 or MI_PRECISION_BF16");
         DeviceGuard g(device);
         m = new mi_clip();
         m->device = device;

@@ -1068,7 +1068,7 @@ __device__ __forceinline__ float xmax_rows(float v) {
 template <int S_PAD, int S_CT, int NQ>
 __device__ __forceinline__ void attn_tiles(const unsigned char* __restrict__ Ks, const unsigned char* __restrict__ Vs,
                                            const bf16_t* __restrict__ base, bf16_t* __restrict__ ctx_b, size_t ld,
-                                           int S_rt, int D, const int (&qt)[NQ], int lane) {
+                                           int S_rt, int D, const int (&qt)[NQ], int lane, int causal = 0) {
     constexpr int NKT = S_PAD / 16, NPV = S_PAD / 32;
     const int S = S_CT > 0 ? S_CT : S_rt;
     const int g = lane >> 4, l15 = lane & 15;
@@ -1122,6 +1122,11 @@ __device__ __forceinline__ void attn_tiles(const unsigned char* __restrict__ Ks,
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (16 * T + 4 * g + e >= S) sc[u][T][e] = -INFINITY;
+                }
+                if (causal) {  // the text tower's mask: key j is visible to query i iff j <= i
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (16 * T + 4 * g + e > qt[u] * 16 + l15) sc[u][T][e] = -INFINITY;
                 }
                 mx = fmaxf(mx, fmaxf(fmaxf(sc[u][T][0], sc[u][T][1]), fmaxf(sc[u][T][2], sc[u][T][3])));
             }
@@ -1210,7 +1215,7 @@ __device__ __forceinline__ void attn_tiles(const unsigned char* __restrict__ Ks,
 template <int S_PAD, int S_CT>
 __device__ __forceinline__ void attn_pair(const unsigned char* __restrict__ Ks, const unsigned char* __restrict__ Vs,
                                           const bf16_t* __restrict__ base, bf16_t* __restrict__ ctx_b, size_t ld,
-                                          int S_rt, int D, int qtA, int qtB, int lane) {
+                                          int S_rt, int D, int qtA, int qtB, int lane, int causal = 0) {
     constexpr int NKT = S_PAD / 16, NPV = S_PAD / 32;
     const int S = S_CT > 0 ? S_CT : S_rt;
     const int g = lane >> 4, l15 = lane & 15;
@@ -1243,7 +1248,7 @@ __device__ __forceinline__ void attn_pair(const unsigned char* __restrict__ Ks, 
         }
     };
     // masked row maximum of a finished score tile set (in-lane + the two cross-lane steps)
-    auto row_max = [&](v4f (&sc)[NKT]) {
+    auto row_max = [&](v4f (&sc)[NKT], int qt) {
         float mx = -INFINITY;
 #pragma unroll
         for (int T = 0; T < NKT; ++T) {
@@ -1252,6 +1257,11 @@ __device__ __forceinline__ void attn_pair(const unsigned char* __restrict__ Ks, 
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (16 * T + 4 * g + e >= S) sc[T][e] = -INFINITY;
+                }
+                if (causal) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (16 * T + 4 * g + e > qt * 16 + l15) sc[T][e] = -INFINITY;
                 }
                 mx = fmaxf(mx, fmaxf(fmaxf(sc[T][0], sc[T][1]), fmaxf(sc[T][2], sc[T][3])));
             }
@@ -1315,7 +1325,7 @@ __device__ __forceinline__ void attn_pair(const unsigned char* __restrict__ Ks, 
         for (int t = 0; t < KPF; ++t)
             if (T0 + KPF + t < NKT && T0 + KPF + t < nkt) load_k(kfr[t], T0 + KPF + t);
     }
-    const float mcA = row_max(scA);
+    const float mcA = row_max(scA, qtA);
     __builtin_amdgcn_sched_barrier(0);
     // ---- QK(B) tile by tile, exp/pack(A) in between
     bf16x8 paA[NPV], paB[NPV];
@@ -1341,7 +1351,7 @@ __device__ __forceinline__ void attn_pair(const unsigned char* __restrict__ Ks, 
             if (T0 + KPF + t < NKT && T0 + KPF + t < nkt) load_k(kfr[t], T0 + KPF + t);
         __builtin_amdgcn_sched_barrier(0);  // keep the written interleave: hipcc otherwise regroups and spills
     }
-    const float mcB = row_max(scB);
+    const float mcB = row_max(scB, qtB);
     __builtin_amdgcn_sched_barrier(0);
     // ---- PV(A) step by step, exp/pack(B) in between
     bf16x8 ones;
@@ -1394,7 +1404,7 @@ __device__ __forceinline__ void attn_pair(const unsigned char* __restrict__ Ks, 
 
 template <int S_PAD, int S_CT>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bf16_kernel(
-    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int S_rt, int D, int H, int q_tiles) {
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int S_rt, int D, int H, int q_tiles, int causal) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ks = smem;
     unsigned char* Vs = smem + S_PAD * 128;
@@ -1433,11 +1443,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     bf16_t* ctx_b = ctx + (size_t)b * S * D + hh * 64;
     int q0 = (wave + blockIdx.x) & 3;
     for (; q0 + 4 < nqt; q0 += 8) {
-        attn_pair<S_PAD, S_CT>(Ks, Vs, base, ctx_b, ld, S_rt, D, q0, q0 + 4, lane);
+        attn_pair<S_PAD, S_CT>(Ks, Vs, base, ctx_b, ld, S_rt, D, q0, q0 + 4, lane, causal);
     }
     if (q0 < nqt) {
         const int one[1] = {q0};
-        attn_tiles<S_PAD, S_CT, 1>(Ks, Vs, base, ctx_b, ld, S_rt, D, one, lane);
+        attn_tiles<S_PAD, S_CT, 1>(Ks, Vs, base, ctx_b, ld, S_rt, D, one, lane, causal);
     }
 }
 

@@ -311,6 +311,29 @@ def test_text_tower_fp32_matches_transformers_golden_and_oracle(built, tmp_path,
     assert np.array_equal(m.embed(many)[-ids.shape[0]:], out)
 
 
+@pytest.mark.parametrize("name,cfg", [("tiny", synth.TextConfig.tiny()), ("l14", synth.TextConfig.clip_l14())])
+def test_text_tower_bf16_within_the_bf16_bound_and_causal(built, tmp_path, name, cfg):
+    """The request-path text tower (bf16 MFMA GEMMs on 77 rows, causal mask in the bf16 attention kernel) against the
+    transformers golden at the bf16 bound of the image tower (3e-2 * rms); fp32 stays the parity path."""
+    from image_search_amd.clip import PRECISION_BF16 as BF16
+    g = np.load(os.path.join(GOLDEN, f"text_{name}.npz"))
+    w = synth.vit_weights(cfg, int(g["seed"]))
+    path = str(tmp_path / "text.safetensors")
+    synth.save_safetensors(w, path, {"num_attention_heads": cfg.heads})
+    ids = synth.token_ids(cfg, int(g["ids_seed"]), int(g["n_seq"]))
+    m = TextModel.from_file(path, 0, BF16)
+    out = m.embed(ids)
+    ok, err = close(out, g["embeds_f64"], 3e-2)
+    assert ok, err
+    print(f"text tower {name} bf16: max|err|/rms = {err:.2e}")
+    ids2 = ids.copy()                         # causality: tokens behind the EOS do not reach the pooled row
+    for i in range(ids2.shape[0]):
+        ids2[i, int(ids2[i].argmax()) + 1:] = 0
+    assert np.array_equal(m.embed(ids2), out)
+    assert np.array_equal(m.embed(np.concatenate([ids] * 3))[-ids.shape[0]:], out)
+    m.close()
+
+
 def test_text_tower_errors_are_codes(built, tmp_path):
     cfg = synth.TextConfig.tiny()
     path = str(tmp_path / "text.safetensors")
@@ -323,7 +346,7 @@ def test_text_tower_errors_are_codes(built, tmp_path):
     assert e.value.code == -1
     from image_search_amd._lib import c_vp, lib
     h = c_vp()
-    assert lib().mi_clip_load_text(path.encode(), 0, PRECISION_BF16, ctypes.byref(h)) == -5       # fp32 only
+    assert lib().mi_clip_load_text(path.encode(), 0, 2, ctypes.byref(h)) == -5                    # no split mode for text
     assert lib().mi_clip_load(path.encode(), 0, PRECISION_F32, ctypes.byref(h)) != 0             # no vision tensors in the file
     out = np.zeros((1, cfg.proj), np.float32)
     assert lib().mi_clip_embed(m._h, out.ctypes.data, 1, out.ctypes.data) == -1                   # image entry point, text handle
