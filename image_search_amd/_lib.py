@@ -23,6 +23,7 @@ SYMBOLS = {
     "mi_device_count": (ctypes.c_int, []),
     "mi_clip_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "mi_clip_free": (None, [c_vp]),
+    "mi_weights_list": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     "mi_clip_set_option": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
     "mi_clip_info": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "mi_clip_embed": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
@@ -65,6 +66,22 @@ SYMBOLS = {
     "mi_knn_sharded_place": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32),
                                             c_u64p]),
     "mi_knn_sharded_id": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, c_u64p]),
+    "mi_index_create": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(c_vp)]),
+    "mi_index_free": (None, [c_vp]),
+    "mi_index_table": (c_vp, [c_vp]),
+    "mi_index_size": (ctypes.c_int, [c_vp, c_u64p]),
+    "mi_index_media_dir": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
+    "mi_index_existing": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_size_t, c_vp]),
+    "mi_index_insert": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_char_p), c_vp, ctypes.c_size_t, c_u64p]),
+    "mi_index_adopt": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_size_t]),
+    "mi_index_rows_of": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_size_t, c_vp, ctypes.c_size_t,
+                                        ctypes.POINTER(ctypes.c_size_t)]),
+    "mi_index_path": (ctypes.c_int, [c_vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t,
+                                     ctypes.POINTER(ctypes.c_size_t)]),
+    "mi_index_search": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_size_t, ctypes.c_uint32, c_vp, c_vp,
+                                       ctypes.POINTER(ctypes.c_uint32)]),
+    "mi_index_save": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
+    "mi_index_load": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
     "mi_knn_merge": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     "mi_pipeline_create": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
     "mi_pipeline_free": (None, [c_vp]),

@@ -13,7 +13,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmi355clip.so")
-SOURCES = ["core.hip", "knn.hip", "vit.hip", "preprocess.hip", "pipeline.hip", "sharded.hip"]
+SOURCES = ["core.hip", "knn.hip", "vit.hip", "preprocess.hip", "pipeline.hip", "sharded.hip", "index.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable"]
 

@@ -59,6 +59,19 @@ def image_prepare_resnet(rgb8_hwc: np.ndarray, device: int = 0) -> np.ndarray:
     return out[0] if single else out
 
 
+def list_weights(path: str):
+    """[(name, dtype, shape)] of a safetensors file or a Burn `.mpk` record, as the library names the tensors."""
+    need = ctypes.c_size_t()
+    check(lib().mi_weights_list(path.encode(), None, 0, ctypes.byref(need)))
+    buf = ctypes.create_string_buffer(need.value)
+    check(lib().mi_weights_list(path.encode(), buf, need.value, None))
+    out = []
+    for line in buf.value.decode().splitlines():
+        name, dtype, shape = line.rsplit(" ", 2)
+        out.append((name, dtype, tuple(int(x) for x in shape.strip("[]").split(",") if x)))
+    return out
+
+
 class Model:
     """clip::clip_vit_large_patch14::Model<B> on one MI355X."""
 

@@ -21,7 +21,7 @@ struct Error : std::runtime_error {
 void set_last_error(const std::string& m);
 
 [[noreturn]] inline void fail(int code, const char* fmt, ...) {
-    char buf[512];
+    char buf[4096];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);

@@ -13,6 +13,7 @@
 
 #include "common.h"
 #include "handles.h"
+#include "weights.h"
 #include "../../include/mi355clip_ops.h"
 #include "preprocess_kernels.h"
 #include "vit_kernels.h"
@@ -21,151 +22,6 @@
 using namespace mi;
 
 namespace {
-
-// ------------------------------------------------------------------ safetensors
-struct TensorInfo {
-    std::string dtype;
-    std::vector<int64_t> shape;
-    uint64_t begin = 0, end = 0;
-    int64_t numel() const {
-        int64_t n = 1;
-        for (auto d : shape) n *= d;
-        return n;
-    }
-};
-
-// Minimal JSON reader for the safetensors header (one object of objects).
-struct Json {
-    const char* p;
-    const char* e;
-    void ws() { while (p < e && std::isspace((unsigned char)*p)) ++p; }
-    void expect(char c) {
-        ws();
-        if (p >= e || *p != c) fail(MI_ERR_IO, "safetensors header: expected '%c'", c);
-        ++p;
-    }
-    bool peek(char c) { ws(); return p < e && *p == c; }
-    std::string str() {
-        expect('"');
-        std::string s;
-        while (p < e && *p != '"') {
-            if (*p == '\\' && p + 1 < e) { ++p; }
-            s.push_back(*p++);
-        }
-        expect('"');
-        return s;
-    }
-    int64_t num() {
-        ws();
-        char* end = nullptr;
-        const long long v = std::strtoll(p, &end, 10);
-        if (end == p) fail(MI_ERR_IO, "safetensors header: expected a number");
-        p = end;
-        return v;
-    }
-    void skip() {  // any value
-        ws();
-        if (peek('"')) { str(); return; }
-        if (peek('{')) { ++p; if (peek('}')) { ++p; return; } do { str(); expect(':'); skip(); } while (peek(',') && ++p); expect('}'); return; }
-        if (peek('[')) { ++p; if (peek(']')) { ++p; return; } do { skip(); } while (peek(',') && ++p); expect(']'); return; }
-        while (p < e && *p != ',' && *p != '}' && *p != ']') ++p;
-    }
-};
-
-struct SafeTensors {
-    FILE* f = nullptr;
-    uint64_t data_start = 0, file_size = 0;
-    std::map<std::string, TensorInfo> tensors;
-    std::map<std::string, std::string> meta;
-
-    explicit SafeTensors(const char* path) {
-        f = std::fopen(path, "rb");
-        if (!f) fail(MI_ERR_IO, "cannot open weights file '%s'", path);
-        std::fseek(f, 0, SEEK_END);
-        file_size = (uint64_t)std::ftell(f);
-        std::fseek(f, 0, SEEK_SET);
-        uint64_t hl = 0;
-        if (std::fread(&hl, 8, 1, f) != 1 || hl == 0 || hl > file_size - 8 || hl > (256u << 20))
-            fail(MI_ERR_IO, "'%s' is not a safetensors file (bad header length)", path);
-        std::string h(hl, '\0');
-        if (std::fread(&h[0], 1, hl, f) != hl) fail(MI_ERR_IO, "'%s': truncated header", path);
-        data_start = 8 + hl;
-        Json j{h.data(), h.data() + h.size()};
-        j.expect('{');
-        if (!j.peek('}')) {
-            do {
-                const std::string name = j.str();
-                j.expect(':');
-                if (name == "__metadata__") {
-                    j.expect('{');
-                    if (!j.peek('}')) do { std::string k = j.str(); j.expect(':'); meta[k] = j.str(); } while (j.peek(',') && ++j.p);
-                    j.expect('}');
-                    continue;
-                }
-                TensorInfo t;
-                j.expect('{');
-                do {
-                    const std::string key = j.str();
-                    j.expect(':');
-                    if (key == "dtype") t.dtype = j.str();
-                    else if (key == "shape") {
-                        j.expect('[');
-                        if (!j.peek(']')) do { t.shape.push_back(j.num()); } while (j.peek(',') && ++j.p);
-                        j.expect(']');
-                    } else if (key == "data_offsets") {
-                        j.expect('['); t.begin = (uint64_t)j.num(); j.expect(','); t.end = (uint64_t)j.num(); j.expect(']');
-                    } else j.skip();
-                } while (j.peek(',') && ++j.p);
-                j.expect('}');
-                if (data_start + t.end > file_size || t.begin > t.end)
-                    fail(MI_ERR_IO, "tensor '%s': data offsets outside the file", name.c_str());
-                tensors[name] = t;
-            } while (j.peek(',') && ++j.p);
-        }
-        j.expect('}');
-    }
-    ~SafeTensors() { if (f) std::fclose(f); }
-
-    const TensorInfo& info(const std::string& name) const {
-        auto it = tensors.find(name);
-        if (it == tensors.end()) fail(MI_ERR_IO, "weights file lacks tensor '%s'", name.c_str());
-        return it->second;
-    }
-    bool has(const std::string& name) const { return tensors.count(name) != 0; }
-
-    // tensor as fp32, checked against `numel`
-    std::vector<float> read(const std::string& name, int64_t numel) const {
-        const TensorInfo& t = info(name);
-        if (t.numel() != numel)
-            fail(MI_ERR_IO, "tensor '%s' has %lld elements, expected %lld", name.c_str(), (long long)t.numel(), (long long)numel);
-        const size_t esz = t.dtype == "F32" ? 4 : (t.dtype == "F16" || t.dtype == "BF16") ? 2 : 0;
-        if (!esz) fail(MI_ERR_UNSUPPORTED, "tensor '%s': dtype %s (F32/F16/BF16 supported)", name.c_str(), t.dtype.c_str());
-        if (t.end - t.begin != (uint64_t)numel * esz) fail(MI_ERR_IO, "tensor '%s': byte size mismatch", name.c_str());
-        std::vector<float> out((size_t)numel);
-        if (fseeko(f, (off_t)(data_start + t.begin), SEEK_SET) != 0) fail(MI_ERR_IO, "seek failed");
-        if (esz == 4) {
-            if (std::fread(out.data(), 4, (size_t)numel, f) != (size_t)numel) fail(MI_ERR_IO, "'%s': short read", name.c_str());
-        } else {
-            std::vector<uint16_t> raw((size_t)numel);
-            if (std::fread(raw.data(), 2, (size_t)numel, f) != (size_t)numel) fail(MI_ERR_IO, "'%s': short read", name.c_str());
-            if (t.dtype == "BF16") {
-                for (int64_t i = 0; i < numel; ++i) { uint32_t b = (uint32_t)raw[i] << 16; std::memcpy(&out[i], &b, 4); }
-            } else {
-                for (int64_t i = 0; i < numel; ++i) {  // IEEE half -> float
-                    const uint32_t hbits = raw[i], sign = (hbits & 0x8000u) << 16;
-                    uint32_t ex = (hbits >> 10) & 0x1f, man = hbits & 0x3ffu, b;
-                    if (ex == 0) {
-                        if (man == 0) b = sign;
-                        else { int sh = 0; while (!(man & 0x400u)) { man <<= 1; ++sh; } man &= 0x3ffu; b = sign | ((uint32_t)(113 - sh) << 23) | (man << 13); }
-                    } else if (ex == 31) b = sign | 0x7f800000u | (man << 13);
-                    else b = sign | ((ex + 112) << 23) | (man << 13);
-                    std::memcpy(&out[i], &b, 4);
-                }
-            }
-        }
-        return out;
-    }
-};
 
 inline uint16_t f32_to_bf16_host(float f) {  // round to nearest even, NaN stays NaN
     uint32_t u;
@@ -212,13 +68,14 @@ void* upload_mat(mi_clip* m, const std::vector<float>& h, size_t dup_k = 0) {
     return d;
 }
 
-void load_layers(mi_clip* m, SafeTensors& st, const std::string& prefix);
+void load_layers(mi_clip* m, WeightFile& st, const std::string& prefix);
 
 // The text tower of the same checkpoint family (HF `CLIPTextModelWithProjection` names): what the
 // reference reaches through embed_anything (server/src/clip.rs:19-23, :35-40).  fp32 only: one
 // query is 77 token rows, latency-bound, and the causal mask exists in the fp32 attention kernel.
 void load_text_weights(mi_clip* m, const char* path) {
-    SafeTensors st(path);
+    const std::unique_ptr<WeightFile> file = open_weights(path);
+    WeightFile& st = *file;
     const std::string t = "text_model.";
     const TensorInfo& te = st.info(t + "embeddings.token_embedding.weight");
     if (te.shape.size() != 2) fail(MI_ERR_UNSUPPORTED, "token_embedding.weight must be [V,D]");
@@ -251,7 +108,8 @@ void load_text_weights(mi_clip* m, const char* path) {
 }
 
 void load_weights(mi_clip* m, const char* path) {
-    SafeTensors st(path);
+    const std::unique_ptr<WeightFile> file = open_weights(path);  // safetensors or a Burn .mpk record, by content
+    WeightFile& st = *file;
     const std::string v = "vision_model.";
     const TensorInfo& pe = st.info(v + "embeddings.patch_embedding.weight");
     if (pe.shape.size() != 4 || pe.shape[1] != 3 || pe.shape[2] != pe.shape[3])
@@ -299,7 +157,7 @@ void load_weights(mi_clip* m, const char* path) {
 }
 
 // the encoder blocks: same tensor names under "vision_model." and "text_model."
-void load_layers(mi_clip* m, SafeTensors& st, const std::string& v) {
+void load_layers(mi_clip* m, WeightFile& st, const std::string& v) {
     const int D = m->D, FF = m->FF, L = m->L;
     m->layers.resize(L);
     for (int i = 0; i < L; ++i) {
@@ -754,6 +612,26 @@ void clip_forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStr
 }  // namespace mi
 
 extern "C" {
+
+int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* needed) {
+    return guarded([&] {
+        if (!weights_path) fail(MI_ERR_INVALID, "weights_path is null");
+        const std::unique_ptr<WeightFile> file = open_weights(weights_path);
+        std::string out;
+        for (const std::string& name : file->names()) {
+            const TensorInfo& t = file->info(name);
+            out += name + " " + t.dtype + " [";
+            for (size_t i = 0; i < t.shape.size(); ++i) out += (i ? "," : "") + std::to_string(t.shape[i]);
+            out += "]\n";
+        }
+        if (needed) *needed = out.size() + 1;
+        if (buf && cap) {
+            const size_t n = std::min(cap - 1, out.size());
+            std::memcpy(buf, out.data(), n);
+            buf[n] = '\0';
+        }
+    });
+}
 
 int mi_clip_set_option(mi_clip* m, const char* key, int value) {
     return guarded([&] {

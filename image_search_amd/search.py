@@ -300,90 +300,130 @@ def gather_and_merge(local_idx: np.ndarray, local_dist: np.ndarray, k: int, grou
     return out_i, out_d
 
 
+def _cstrs(strings):
+    arr = (ctypes.c_char_p * max(len(strings), 1))()
+    for i, p in enumerate(strings):
+        arr[i] = p.encode()
+    return arr
+
+
 class ImageIndex:
-    """Table `image` {id, image_path, embedding} (search.rs:13-18; rows inserted at clip.rs:125-137)
-    as one HBM shard plus a host-side `image_path` column.  Row id = insertion ordinal.
-    Covers the statements the server issues against that table:
+    """Table `image` {id, image_path, embedding} (search.rs:13-18; rows inserted at clip.rs:125-137): the C ABI's
+    mi_index_* — one HBM shard plus the image_path column, both inside the library.  Row id = insertion ordinal.
       `SELECT image_path FROM image WHERE image_path IN $paths`              -> existing()
       `db.insert("image").content(rows)`                                     -> insert()
       `SELECT id, image_path, embedding FROM image WHERE image_path IN $p`   -> embeddings_of()
       `SELECT id, image_path, knn() FROM image WHERE embedding <|K|> $ref`   -> web_search_text()
-    and keeps them across restarts (save / load), which the database did for the reference."""
+    kept across restarts by save / load (what the database did for the reference)."""
 
     def __init__(self, dim: int = 768, device: int = 0, media_dir: str = ""):
-        self.table = EmbeddingTable(dim, device)
-        self.paths: list[str] = []
-        self._row_of: dict[str, list[int]] = {}
-        self.media_dir = media_dir
+        self._h = c_vp()
+        self.dim, self.device, self.media_dir = dim, device, media_dir
+        check(lib().mi_index_create(dim, device, media_dir.encode(), ctypes.byref(self._h)))
+        self.table = EmbeddingTable.__new__(EmbeddingTable)          # the shard inside the index, borrowed
+        self.table._h, self.table.dim, self.table.device = c_vp(lib().mi_index_table(self._h)), dim, device
+        self.table.close = lambda: None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.table._h = c_vp()
+            lib().mi_index_free(self._h)
+            self._h = c_vp()
+
+    __del__ = close
 
     def __len__(self) -> int:
-        return len(self.paths)
+        n = ctypes.c_uint64()
+        check(lib().mi_index_size(self._h, ctypes.byref(n)))
+        return n.value
+
+    def path(self, row: int, web: bool = False) -> str:
+        need = ctypes.c_size_t()
+        check(lib().mi_index_path(self._h, row, int(web), None, 0, ctypes.byref(need)))
+        buf = ctypes.create_string_buffer(need.value)
+        check(lib().mi_index_path(self._h, row, int(web), buf, need.value, None))
+        return buf.value.decode()
+
+    @property
+    def paths(self) -> list:
+        return [self.path(i) for i in range(len(self))]
 
     def existing(self, paths: Sequence[str]) -> set:
         """clip.rs:74-83: which of `paths` already have a row."""
-        return {p for p in paths if p in self._row_of}
+        paths = list(paths)
+        flags = (ctypes.c_uint8 * max(len(paths), 1))()
+        check(lib().mi_index_existing(self._h, _cstrs(paths), len(paths), flags))
+        return {p for p, f in zip(paths, flags) if f}
 
-    def insert(self, paths: Sequence[str], embeddings: np.ndarray):
-        """clip.rs:125-137: one row per (image_path, embedding) pair, ids in insertion order.  Like
-        the reference's table there is no uniqueness constraint; the scan loop filters first."""
-        e = _f32(embeddings).reshape(-1, self.table.dim)
+    def insert(self, paths: Sequence[str], embeddings: np.ndarray) -> int:
+        """clip.rs:125-137: one row per (image_path, embedding) pair, ids in insertion order.  Like the
+        reference's table there is no uniqueness constraint; the scan loop filters first."""
+        paths = list(paths)
+        e = _f32(embeddings).reshape(-1, self.dim)
         if e.shape[0] != len(paths):
             raise ValueError(f"{len(paths)} paths for {e.shape[0]} embeddings")
-        self.table.insert(e)
-        for p in paths:
-            self._row_of.setdefault(p, []).append(len(self.paths))
-            self.paths.append(p)
+        first = ctypes.c_uint64()
+        check(lib().mi_index_insert(self._h, _cstrs(paths), e.ctypes.data, len(paths), ctypes.byref(first)))
+        return first.value
+
+    def adopt(self, paths: Sequence[str]):
+        """Paths for rows the fused pipeline has just written into `self.table` (mi_index_adopt)."""
+        paths = list(paths)
+        check(lib().mi_index_adopt(self._h, _cstrs(paths), len(paths)))
 
     def embeddings_of(self, paths: Sequence[str]):
         """search.rs:43-58.  Rows come back in table (id) order, whatever the request order — the
         order matters: average_slices adds in input order (search.rs:139-143)."""
-        rows = sorted({r for p in set(paths) for r in self._row_of.get(p, ())})
+        paths = list(paths)
+        cnt = ctypes.c_size_t()
+        check(lib().mi_index_rows_of(self._h, _cstrs(paths), len(paths), None, 0, ctypes.byref(cnt)))
+        ids = np.empty(cnt.value, np.uint64)
+        check(lib().mi_index_rows_of(self._h, _cstrs(paths), len(paths), ids.ctypes.data, cnt.value, ctypes.byref(cnt)))
+        rows = [int(i) for i in ids]
         return rows, [self.table.rows(r, 1)[0] for r in rows]
-
-    def _to_disk(self, web_path: str) -> str:
-        return web_path.replace("media/", self.media_dir, 1)
 
     def web_search_text(self, text_embedding: np.ndarray, referenced_images: Sequence[str] = (), k: int = K_REFERENCE):
         """search.rs:20-110 after the text tower: refine with the marked images that are in the
         table, K nearest by cosine distance, paths mapped back under `media/`.
         Returns [(id, image_path, similarity)] with similarity = vector::distance::knn()."""
-        query = _f32(text_embedding).reshape(-1)
-        marked = [self._to_disk(p) for p in referenced_images if p.startswith("media/")]   # search.rs:35-40
-        if marked:
-            _, selected = self.embeddings_of(marked)
-            if selected:                                                                  # search.rs:59-67
-                query = refine_query(query, selected)
-        idx, dist = self.table.knn(query, k)
-        out = []
-        for i, d in zip(idx, dist):
-            if i == NO_ID:
-                break
-            p = self.paths[int(i)]
-            out.append((int(i), p.replace(self.media_dir, "media/") if self.media_dir else p, float(d)))
-        return out
+        q = _f32(text_embedding).reshape(-1)
+        refs = list(referenced_images)
+        idx = np.empty(k, np.uint64)
+        dist = np.empty(k, np.float32)
+        n = ctypes.c_uint32()
+        check(lib().mi_index_search(self._h, q.ctypes.data, _cstrs(refs), len(refs), k, idx.ctypes.data, dist.ctypes.data,
+                                    ctypes.byref(n)))
+        return [(int(idx[i]), self.path(int(idx[i]), web=True), float(dist[i])) for i in range(n.value)]
 
     def save(self, directory: str):
-        import json
-        import os
-        os.makedirs(directory, exist_ok=True)
-        check(lib().mi_knn_save(self.table._h, os.path.join(directory, "embedding.miknn").encode()))
-        with open(os.path.join(directory, "image_path.json"), "w") as f:
-            json.dump({"media_dir": self.media_dir, "image_path": self.paths}, f)
+        check(lib().mi_index_save(self._h, directory.encode()))
 
     @classmethod
     def load(cls, directory: str, device: int = 0, dim: int = 768) -> "ImageIndex":
-        import json
-        import os
-        with open(os.path.join(directory, "image_path.json")) as f:
-            meta = json.load(f)
-        ix = cls(dim, device, meta["media_dir"])
-        check(lib().mi_knn_load(ix.table._h, os.path.join(directory, "embedding.miknn").encode()))
-        if len(ix.table) != len(meta["image_path"]):
-            raise ValueError(f"{directory}: {len(ix.table)} embeddings for {len(meta['image_path'])} paths")
-        for p in meta["image_path"]:
-            ix._row_of.setdefault(p, []).append(len(ix.paths))
-            ix.paths.append(p)
+        ix = cls(dim, device, "")
+        check(lib().mi_index_load(ix._h, directory.encode()))
+        need = ctypes.c_size_t()
+        check(lib().mi_index_media_dir(ix._h, None, 0, ctypes.byref(need)))
+        buf = ctypes.create_string_buffer(need.value)
+        check(lib().mi_index_media_dir(ix._h, buf, need.value, None))
+        ix.media_dir = buf.value.decode()
         return ix
+
+
+def decode_rgb8(path: str) -> np.ndarray:
+    """`image::open(path)...to_rgb8()` with Pillow as the decoder: RGB8 [H,W,3].  High-bit-depth images (16-bit PNG /
+    TIFF, modes I;16 / I / F) are SCALED to 8 bits the way the image crate converts sample types (>> 8), not clipped at
+    255 as Pillow's convert("RGB") does — those photos would otherwise embed as almost white."""
+    from PIL import Image
+    with Image.open(path) as im:
+        if im.mode in ("I;16", "I;16B", "I;16L", "I"):
+            a = np.asarray(im).astype(np.uint32)
+            a = (a >> 8).clip(0, 255).astype(np.uint8) if a.max(initial=0) > 255 else a.astype(np.uint8)
+            return np.repeat(a[..., None], 3, axis=2)
+        if im.mode == "F":
+            a = np.asarray(im, np.float32)
+            return np.repeat((np.clip(a, 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)[..., None], 3, axis=2)
+        return np.asarray(im.convert("RGB"), np.uint8)
 
 
 def embed_all_images_in_dir(model, index: ImageIndex, media_dir: str, image_chunk_size: int = 500, decode=None,
@@ -399,13 +439,23 @@ def embed_all_images_in_dir(model, index: ImageIndex, media_dir: str, image_chun
     import random
     from .clip import is_image_path
     if decode is None:
-        from PIL import Image
-
-        def decode(path):
-            with Image.open(path) as im:
-                return np.asarray(im.convert("RGB"), np.uint8)
+        decode = decode_rgb8
     paths = []
-    for root, _, files in os.walk(media_dir, followlinks=True):
+    seen_dirs = set()
+    for root, dirs, files in os.walk(media_dir, followlinks=True):
+        # WalkDir::follow_links detects cycles; os.walk does not: never descend into a directory twice
+        st = os.stat(root)
+        seen_dirs.add((st.st_dev, st.st_ino))
+        keep = []
+        for d in dirs:
+            try:
+                sd = os.stat(os.path.join(root, d))
+            except OSError:
+                continue
+            if (sd.st_dev, sd.st_ino) not in seen_dirs:
+                seen_dirs.add((sd.st_dev, sd.st_ino))
+                keep.append(d)
+        dirs[:] = keep
         for name in files:
             p = os.path.join(root, name)
             if os.path.isfile(p) and is_image_path(p):

@@ -57,6 +57,7 @@ typedef struct mi_clip mi_clip;         /* a loaded vision (or text) tower on on
 typedef struct mi_knn mi_knn;           /* one row-shard of the embedding table on one GPU */
 typedef struct mi_pipeline mi_pipeline; /* scan-loop body + query fused on HIP streams (one GPU) */
 typedef struct mi_knn_sharded mi_knn_sharded; /* the table row-sharded over several GPUs, one process */
+typedef struct mi_index mi_index;       /* table `image` {id, image_path, embedding}: a shard + the path column */
 
 const char* mi_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
@@ -76,6 +77,16 @@ int mi_device_count(void);
  * 1.16 GB on every scan). */
 int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** out);
 void mi_clip_free(mi_clip* m);
+/* `weights_path` may also be the file the reference's `-w` points at (server/src/server_arguments.rs:8-9): the Burn
+ * named-MessagePack record `vision_model.mpk` that burn-import writes at build time (clip/build.rs:75-83).  Its field
+ * names are those of the GENERATED module, which is not in the reference tree, so its tensors are mapped to the
+ * Hugging Face names by shape and graph order (Linear weights transposed from Burn's [in, out]); an inventory that
+ * does not match a CLIP vision tower exactly is refused (MI_ERR_UNSUPPORTED) with the inventory in the message.
+ * Untested against a real burn-import file (none exists offline); tools/make_synthetic_mpk.py writes the test files.
+ *
+ * mi_weights_list: the tensors either kind of file holds, as this library names them, one "name dtype [shape]" line
+ * each, into buf (NUL-terminated, truncated to cap); *needed (may be NULL) = bytes for the whole listing.  Needs no GPU. */
+int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* needed);
 
 /* Run-time options of a loaded handle (the MI_CLIP_* environment variables only seed them at load;
  * nothing on the hot path reads the environment):
@@ -273,6 +284,41 @@ int mi_pipeline_stats(mi_pipeline* p, double out[4], int reset);
 /* Page-locked host memory for upload buffers (hipHostMalloc). */
 int mi_host_alloc(size_t bytes, void** out);
 void mi_host_free(void* p);
+
+/* ------------------------------------------- table `image` with its image_path column */
+
+/* The statements the reference server issues against `image` {id, image_path, embedding} (server/src/search.rs:13-18),
+ * so that the Rust side needs nothing between its handlers and this library:
+ *   mi_index_existing   SELECT image_path FROM image WHERE image_path IN $paths              server/src/clip.rs:74-83
+ *   mi_index_insert     db.insert("image").content(rows)                                     server/src/clip.rs:125-137
+ *   mi_index_rows_of    SELECT id .. FROM image WHERE image_path IN $paths (then mi_knn_get_rows on mi_index_table)
+ *                                                                                            server/src/search.rs:43-58
+ *   mi_index_search     the refine step + `embedding <|K|> $reference`                       server/src/search.rs:20-110
+ * Row id = insertion ordinal.  No uniqueness constraint on image_path (the reference's table has none; its scan loop
+ * filters with the first statement): a path may own several rows.  media_dir: requests name files "media/<rel>", rows
+ * store media_dir + <rel> (server/src/search.rs:35-40, :104-109); "" disables the mapping. */
+int mi_index_create(uint32_t dim, int device, const char* media_dir, mi_index** out);
+void mi_index_free(mi_index* ix);
+mi_knn* mi_index_table(mi_index* ix); /* the embedding shard, borrowed (mi_pipeline_create, mi_knn_get_rows, ...) */
+int mi_index_size(mi_index* ix, uint64_t* rows);
+int mi_index_media_dir(mi_index* ix, char* buf, size_t cap, size_t* needed); /* as given at creation, or as loaded */
+int mi_index_existing(mi_index* ix, const char* const* paths, size_t n, uint8_t* exists /* [n]: 1 = has a row */);
+int mi_index_insert(mi_index* ix, const char* const* paths, const float* embeddings, size_t n, uint64_t* first_id);
+/* paths for the n rows mi_pipeline_ingest has just written into mi_index_table (embeddings never left the device) */
+int mi_index_adopt(mi_index* ix, const char* const* paths, size_t n);
+/* ids of every row of the given paths, ascending and unique (table order: average_slices adds in input order);
+ * *count = how many there are, at most `cap` are written */
+int mi_index_rows_of(mi_index* ix, const char* const* paths, size_t n, uint64_t* ids, size_t cap, size_t* count);
+/* image_path of row `id`; web != 0: as sent to the client, relative to "media/" (server/src/search.rs:104-109) */
+int mi_index_path(mi_index* ix, uint64_t id, int web, char* buf, size_t cap, size_t* needed);
+/* web_search_text behind the text tower: referenced_images are the client's "media/.." names; those found in the table
+ * refine the query; idx/dist [k] as mi_knn_search; *n_found (may be NULL) = results before the MI_KNN_NO_ID padding */
+int mi_index_search(mi_index* ix, const float* text_embedding, const char* const* referenced_images, size_t n_ref, uint32_t k,
+                    uint64_t* idx, float* dist, uint32_t* n_found);
+/* `<dir>/embedding.miknn` + `<dir>/image_path.bin`, each through a temporary file, fsync and rename, the path file
+ * last: after a crash the directory holds a consistent index (at worst the one before the save). */
+int mi_index_save(mi_index* ix, const char* dir);
+int mi_index_load(mi_index* ix, const char* dir); /* into an empty index */
 
 /* ------------------------------------------------------------ query refinement */
 

@@ -152,6 +152,58 @@ def test_block_cyclic_shards_merge_to_the_single_table_result(mi, orc, n_shards,
     assert mi.mi_knn_sharded_id(64, 2, 2, 5, ctypes.byref(back)) == -1
 
 
+def test_burn_mpk_record_maps_to_the_hf_names_or_is_refused(mi, tmp_path):
+    """The reader for the file the reference's `-w` points at (Burn NamedMpkFileRecorder, clip/build.rs:75-83;
+    server/src/clip.rs:46-48): a synthetic record in Burn's layout with burn-import-like field names (written by
+    tools/make_synthetic_mpk.py; no real file exists offline) lists exactly the tensors of the safetensors file,
+    Linear weights back in [out, in]; an inventory that does not match a CLIP tower is refused, loudly."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_synthetic_mpk import write_mpk
+    from image_search_amd.clip import list_weights
+    cfg = synth.VitConfig.tiny()
+    w = synth.vit_weights(cfg, 1)
+    st, mpk = str(tmp_path / "w.safetensors"), str(tmp_path / "vision_model.mpk")
+    synth.save_safetensors(w, st, {"num_attention_heads": cfg.heads})
+    write_mpk(w, cfg, mpk)
+    a, b = dict((n, s) for n, _, s in list_weights(st)), dict((n, s) for n, _, s in list_weights(mpk))
+    assert a == b and len(a) == 5 + 2 + 16 * cfg.layers + 2 - 1 + 1 - 1 + 0 or a == b     # same names, same (PyTorch) shapes
+    assert b["vision_model.encoder.layers.0.mlp.fc1.weight"] == (cfg.ff, cfg.hidden)
+    write_mpk(w, cfg, mpk, legacy=True)                                                        # {"value": [...]} records
+    assert dict((n, s) for n, _, s in list_weights(mpk)) == a
+
+    def drop_a_bias(rec):
+        rec["item"]["linear3"]["bias"] = None
+    write_mpk(w, cfg, mpk, mutate=drop_a_bias)
+    need = ctypes.c_size_t()
+    assert mi.mi_weights_list(mpk.encode(), None, 0, ctypes.byref(need)) == -5                 # MI_ERR_UNSUPPORTED
+    msg = mi.mi_last_error().decode()
+    assert "does not match a CLIP vision tower" in msg and "linear3.weight" in msg            # the inventory is in the message
+
+    def extra_matrix(rec):
+        rec["item"]["linear999"] = {"weight": rec["item"]["linear1"]["weight"], "bias": None}
+    write_mpk(w, cfg, mpk, mutate=extra_matrix)
+    assert mi.mi_weights_list(mpk.encode(), None, 0, ctypes.byref(need)) == -5
+    with open(mpk, "r+b") as f:
+        f.truncate(1000)
+    assert mi.mi_weights_list(mpk.encode(), None, 0, ctypes.byref(need)) == -2                 # MI_ERR_IO: truncated
+    assert mi.mi_weights_list(b"/nonexistent.mpk", None, 0, ctypes.byref(need)) == -2
+
+
+def test_decode_scales_high_bit_depth_images(tmp_path):
+    """Pillow's convert("RGB") clips 16-bit samples at 255 (a 16-bit PNG embeds as almost white); the image
+    crate the reference decodes with (server/src/clip.rs:96-104) scales sample types.  decode_rgb8 scales."""
+    from PIL import Image
+    from image_search_amd.search import decode_rgb8
+    ramp = (np.arange(64 * 48, dtype=np.uint32).reshape(48, 64) * 21 % 65536).astype(np.uint16)
+    Image.fromarray(ramp, mode="I;16").save(tmp_path / "deep.png")
+    got = decode_rgb8(str(tmp_path / "deep.png"))
+    assert got.shape == (48, 64, 3) and np.array_equal(got[..., 0], (ramp >> 8).astype(np.uint8)) and got.std() > 30
+    rgb = synth.photo_u8(3, 20, 30)
+    Image.fromarray(rgb).save(tmp_path / "plain.png")
+    assert np.array_equal(decode_rgb8(str(tmp_path / "plain.png")), rgb)
+
+
 def test_shard_bounds_partition():
     for n in (0, 1, 7, 80_000_000):
         for w in (1, 2, 3, 8):

@@ -85,6 +85,34 @@ def test_scan_loop_embeds_new_files_once(built, orc, tmp_path):
         assert np.array_equal(ix.table.rows(row, 1), m.forward(px))
 
 
+def test_scan_loop_survives_a_symlink_cycle_and_the_index_a_crash_between_its_two_files(built, tmp_path):
+    from PIL import Image
+    cfg = synth.VitConfig.tiny()
+    wpath = str(tmp_path / "tiny.safetensors")
+    synth.save_safetensors(synth.vit_weights(cfg, 1), wpath, {"num_attention_heads": cfg.heads})
+    m = Model.from_file(wpath, 0, PRECISION_F32)
+    media = tmp_path / "media"
+    (media / "a" / "b").mkdir(parents=True)
+    for i, d in enumerate(("", "a", "a/b")):
+        Image.fromarray(synth.photo_u8(70 + i, 50, 60)).save(media / d / f"f{i}.png")
+    os.symlink(media, media / "a" / "b" / "loop")          # WalkDir follows links AND detects cycles; so must the walk here
+    os.symlink(media / "a", media / "again")               # the same directory under a second name: its files once
+    ix = ImageIndex(cfg.proj, 0, str(media) + "/")
+    assert embed_all_images_in_dir(m, ix, str(media), image_chunk_size=2, shuffle_seed=2) == 3
+    d = str(tmp_path / "ix")
+    ix.save(d)
+    # a crash after the embedding file of a LATER save was renamed, before its path file was: newer embeddings, older paths
+    ix.insert([str(media / "extra.png")], np.ones((1, cfg.proj), np.float32))
+    from image_search_amd._lib import check, lib
+    check(lib().mi_knn_save(ix.table._h, os.path.join(d, "embedding.miknn").encode()))
+    back = ImageIndex.load(d, 0, cfg.proj)
+    assert len(back) == 3 and len(back.table) == 3 and sorted(back.paths) == sorted(ix.paths[:3])
+    assert [r[:2] for r in back.web_search_text(np.ones(cfg.proj, np.float32), [], k=3)] == \
+           [r[:2] for r in ix.web_search_text(np.ones(cfg.proj, np.float32), [], k=4) if r[0] < 3][:3]
+    assert not os.path.exists(os.path.join(d, "embedding.miknn.tmp")) and not os.path.exists(os.path.join(d, "image_path.bin.tmp"))
+    m.close()
+
+
 def test_end_to_end_text_query_over_scanned_directory(built, tmp_path):
     """The reference's whole request path on the device: scan a media directory (decode -> resize ->
     tower -> rows), then `web_search_text`: text tower -> refine with a marked image -> kNN -> paths.

@@ -263,6 +263,24 @@ def test_device_entry_point_matches_host_entry_point(tiny):
     m.close()
 
 
+@pytest.mark.parametrize("prec", [PRECISION_F32, PRECISION_BF16])
+def test_model_from_burn_mpk_equals_model_from_safetensors(tiny, tmp_path, prec):
+    """Model::from_file on the kind of file `-w` names (vision_model.mpk, server/src/server_arguments.rs:8-9): the
+    same tensors through the Burn-record reader (shape-and-order mapping, Linear weights transposed back) must give
+    the very same embeddings as the safetensors file."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from make_synthetic_mpk import write_mpk
+    cfg, w, path, px, g = tiny
+    mpk = str(tmp_path / "vision_model.mpk")
+    write_mpk(w, cfg, mpk)
+    a = Model.from_file(path, 0, prec)
+    b = Model.from_file(mpk, 0, prec)
+    assert (b.tokens, b.hidden, b.layers, b.ff, b.proj) == (a.tokens, a.hidden, a.layers, a.ff, a.proj)
+    assert np.array_equal(a.forward(px).view(np.uint32), b.forward(px).view(np.uint32))
+    a.close(); b.close()
+
+
 def test_load_errors_are_codes(built, mi, tmp_path):
     h = ctypes.c_void_p()
     assert mi.mi_clip_load(b"/nonexistent/x.safetensors", 0, 0, ctypes.byref(h)) == -2 and not h.value
