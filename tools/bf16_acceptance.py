@@ -6,6 +6,9 @@
      as generated (HF init scales) and with planted outlier channels (x50 on four LayerNorm gains, the
      shape trained CLIP towers have).  error = max |bf16 - fp32| / rms(fp32), and the cosine distance
      between the two embeddings of one image against the distance to its nearest OTHER image.
+     (profiles/r02_bf16_acceptance.json also holds a third mode, a bf16 RESIDUAL stream, built for that run and then
+     removed: 3x the error for no speed — 40.99 vs 40.65 ms per 256 images; the LayerNorms it was meant to relieve
+     already overlap the other half-chunk's GEMMs.)
 (ii) retrieval: the same images indexed twice (fp32 embeddings, bf16 embeddings); held-out query images
      embedded in the index's own precision; top-1 / top-10 / top-1000 id agreement between the two systems.
 """
@@ -85,12 +88,21 @@ def timing(weights, cfg, px):
     out = {}
     try:
         for name, prec in (("MI_PRECISION_BF16", PRECISION_BF16), ("MI_PRECISION_BF16_SPLIT", PRECISION_BF16_SPLIT)):
+            import torch
             m = Model.from_file(path, 0, prec)
-            m.forward(px)
-            t0 = time.perf_counter()
-            for _ in range(5):
-                m.forward(px)
-            out[name] = round((time.perf_counter() - t0) / 5 * 1e3, 2)   # host pointers: includes the 147 MiB upload
+            d_in = torch.from_numpy(px).cuda()
+            d_out = torch.empty((len(px), 768), dtype=torch.float32, device="cuda")
+            st = torch.cuda.Stream()
+            for _ in range(3):
+                m.forward_device(d_in.data_ptr(), len(px), d_out.data_ptr(), st.cuda_stream)
+            st.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st)
+            for _ in range(10):
+                m.forward_device(d_in.data_ptr(), len(px), d_out.data_ptr(), st.cuda_stream)
+            b.record(st)
+            st.synchronize()
+            out[name] = round(a.elapsed_time(b) / 10, 3)   # inputs resident, HIP events on the launch stream
             m.close()
     finally:
         os.unlink(path)

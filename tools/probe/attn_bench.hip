@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
     {
         auto kern = attn_bf16_kernel<288, 257>;
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 288 * 256));
-        const float us = time_us([&] { hipLaunchKernelGGL(kern, dim3(n * H), dim3(256), 288 * 256, 0, qkv, ctx, S, D, H, 0); }, 20);
+        const float us = time_us([&] { hipLaunchKernelGGL(kern, dim3(n * H), dim3(256), 288 * 256, 0, qkv, ctx, S, D, H, 0, 0); }, 20);
         printf("attn_bf16<288,257> (16-query tiles) n=%d: %.1f us per launch\n", n, us);
     }
     return 0;
