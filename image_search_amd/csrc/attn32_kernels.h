@@ -27,10 +27,8 @@
 //    [-55, +69].  tests/test_vit_gpu.py drives both sides of the window.
 //    log2(e)/8 is folded into q: by mi_clip_load into W_q / b_q before their bf16 rounding (PRESCALED),
 //    or here on the query fragments (the op-level test hook hands over plain q).
-//  * 257 = 8 x 32 + 1: the four waves take the eight full tiles in pairs and then SPLIT the ninth tile
-//    (one live query) over the key tiles, partial sums combined through LDS — numerators need no
-//    rescaling between waves because there is no per-wave maximum.  The same split serves the last
-//    layer (only the CLS row's tile is needed there).
+//  * 257 = 8 x 32 + 1: eight waves take the eight full tiles and the ninth tile (one live query) is SPLIT over
+//    the key tiles into per-tile partials combined through LDS (attn32_bf16_kernel below).
 //
 // LDS image of K and V: [S_PAD][64] bf16, 128-byte rows, 16-byte chunk c of row r stored at chunk
 // position c ^ swz32(r), swz32(r) = ((r >> 1) & 1) << 2 | ((r >> 2) & 3): conflict-free for the
@@ -57,6 +55,15 @@ __device__ __forceinline__ bf16x8 pack8(const v16f& s, int base) {
 }
 
 constexpr float ATTN32_C2 = 0.125f * 1.4426950408889634f;  // scale * log2(e)
+
+// Diagnostic builds only (tools/probe/attn_bench.hip -DATTN32_ABL=mask): take one cost out of the static sweep to
+// see what it was worth.  1 no exp2, 2 numerators not packed (constant P; keeps the score MFMAs alive), 4 K/V
+// fragments read from LDS once per tile sweep, 8 no row-sum MFMAs, 16 waves 4-7 skip their whole tile, 32 no split
+// tile, 64 no LDS-DMA after the first pair, 128 no ctx stores, 256 query loads with coalesced addresses (8 lanes
+// per row), 512 ctx stores with coalesced addresses.  Results are wrong by construction; the library is built with 0.
+#ifndef ATTN32_ABL
+#define ATTN32_ABL 0
+#endif
 
 // One query tile swept over the key tiles t0, t0 + tstep, ... < nkt, software-pipelined: the scores of
 // the NEXT key tile (4 MFMAs) are issued between the four slices of the current tile's numerators
@@ -200,6 +207,7 @@ __device__ __forceinline__ void attn32_sweep_static(const unsigned char* __restr
 #pragma unroll
     for (int e = 0; e < 16; ++e) lsum[e] = 0.0f;
     bf16x8 kf[2][4];  // K fragments of tile t + 1 (in use) and t + 2 (landing): LDS latency never meets an MFMA
+    bf16x8 vf[2][2];
     v16f sc[2];
     auto load_k = [&](bf16x8 (&dst)[4], int t) {
 #pragma unroll
@@ -218,10 +226,10 @@ __device__ __forceinline__ void attn32_sweep_static(const unsigned char* __restr
         const bool last = t + 1 == NKT;
         const bool one_key = last && ONE_KEY;
         const bool ragged = last && (S_CT % 32) != 0;
-        bf16x8 (&kn)[4] = kf[(t + 1) & 1];  // tile t + 1, read during step t - 1
-        bf16x8 vf[2][2];
+        bf16x8 (&kn)[4] = kf[(ATTN32_ABL & 4) ? 0 : (t + 1) & 1];  // tile t + 1, read during step t - 1
         hook();  // the caller's per-step work (one piece of the next pair's LDS-DMA)
         // this step's V fragments (used by its last MFMAs) and the K fragments of the step after next, up front
+        if (!(ATTN32_ABL & 4) || t == 0)
 #pragma unroll
         for (int kp = 0; kp < (one_key ? 1 : 2); ++kp)
 #pragma unroll
@@ -250,7 +258,7 @@ __device__ __forceinline__ void attn32_sweep_static(const unsigned char* __restr
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int e = 4 * ks + j;
-                    float p = __builtin_amdgcn_exp2f(cur[e]);
+                    float p = (ATTN32_ABL & 1) ? cur[e] : __builtin_amdgcn_exp2f(cur[e]);
                     if (ragged) {
                         const int key = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
                         p = key < S_CT ? p : 0.0f;
@@ -262,84 +270,130 @@ __device__ __forceinline__ void attn32_sweep_static(const unsigned char* __restr
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < NKT) load_k(kf[t & 1], t + 2);  // the slot of tile t is free once its scores exist (previous step)
-        const bf16x8 p0 = pack8(cur, 0);
+        if (t + 2 < NKT && !(ATTN32_ABL & 4)) load_k(kf[t & 1], t + 2);  // the slot of tile t is free once its scores exist (previous step)
+        bf16x8 p0 = pack8(cur, 0);
+        if (ATTN32_ABL & 2) { p0 = ones; p0[0] = (__bf16)cur[0]; }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][0], p0, o[dt], 0, 0, 0);
-        lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p0, lsum, 0, 0, 0);
+        if (!(ATTN32_ABL & 8)) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p0, lsum, 0, 0, 0);
         if (!one_key) {
-            const bf16x8 p1 = pack8(cur, 8);
+            bf16x8 p1 = pack8(cur, 8);
+            if (ATTN32_ABL & 2) { p1 = ones; p1[0] = (__bf16)cur[8]; }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][1], p1, o[dt], 0, 0, 0);
-            lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p1, lsum, 0, 0, 0);
+            if (!(ATTN32_ABL & 8)) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p1, lsum, 0, 0, 0);
         }
     }
-    l += lsum[0];  // every row of ones x P is the column sum over all keys: complete in every lane
+    l += (ATTN32_ABL & 8) ? 1.0f : lsum[0];  // every row of ones x P is the column sum over all keys: complete in every lane
 }
 
-// One key tile of one query tile in online-softmax form (the split query's shares): scores, their maximum,
-// rescale of what this wave has accumulated so far, numerators against the running maximum, P V.
-// m_run = running maximum of this lane's query (-inf before the first tile); l complete in every lane.
-template <int S_CT>
-__device__ __forceinline__ void attn32_tile_online(const unsigned char* __restrict__ Ks, const unsigned char* __restrict__ Vs,
-                                                   const bf16x8 (&qf)[4], int S_rt, int t, int lane, v16f (&o)[2], float& l,
-                                                   float& m_run) {
-    const int S = S_CT > 0 ? S_CT : S_rt;
+// The split query's partial over ONE full key tile, two tiles at a time (independent chains interleave): scores, the
+// tile's own maximum, numerators against it, P V from zero.  Nothing is carried from tile to tile — a partial is
+// (O_t, l_t, m_t) and the combine weighs it by 2^(m_t - M) — so any wave can take any tile and there is no rescale
+// of a running output.  part: this pair's partials, [tile][lane half][ATTN32_PROW] f32 = 32 O + l + m.
+constexpr int ATTN32_PROW = 36;  // 34 used; 144-byte rows keep the 16-byte stores aligned
+__device__ __forceinline__ void attn32_split_tiles(const unsigned char* __restrict__ Ks, const unsigned char* __restrict__ Vs,
+                                                   const bf16x8 (&qf)[4], int ta, int tb, int lane, float* __restrict__ part) {
     const int r = lane & 31, h = lane >> 5;
     const int g16 = lane >> 4, vq = (lane & 15) >> 2, vp = lane & 3;
     const int vc = 2 * (g16 & 1) + (vp >> 1);
-    const unsigned char* kb = Ks + 4096 * t;
-    const unsigned char* vb = Vs + 4096 * t;
+    const int tt[2] = {ta, tb};
+    bf16x8 kf[2][4], vf[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            kf[i][ks] = *reinterpret_cast<const bf16x8*>(Ks + 4096 * tt[i] + r * 128 + (((2 * ks + h) ^ swz32(r)) << 4));
+    v16f s[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[i][e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][ks], qf[ks], s[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int row0 = 4 * h + vq, row1 = row0 + 8;
+                const unsigned char* vb = Vs + 4096 * tt[i] + 2048 * kp;
+                const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(
+                    vb + row0 * 128 + (((4 * dt + vc) ^ swz32(row0)) << 4) + 8 * (vp & 1)));
+                const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(
+                    vb + row1 * 128 + (((4 * dt + vc) ^ swz32(row1)) << 4) + 8 * (vp & 1)));
+                vf[i][dt][kp] = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    float m[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float mx = fmaxf(s[i][0], s[i][1]);
+#pragma unroll
+        for (int e = 2; e < 16; e += 2) mx = fmaxf(mx, fmaxf(s[i][e], s[i][e + 1]));  // v_max3
+        m[i] = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[i][e] = __builtin_amdgcn_exp2f(s[i][e] - m[i]);
+        const bf16x8 p0 = pack8(s[i], 0), p1 = pack8(s[i], 8);
+        v16f o[2], ls;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[0][e] = o[1][e] = ls[e] = 0.0f;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i][dt][0], p0, o[dt], 0, 0, 0);
+        ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p0, ls, 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i][dt][1], p1, o[dt], 0, 0, 0);
+        ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p1, ls, 0, 0, 0);
+        if (r == 0) {  // every query column of the tile is the one live row: column 0 speaks for it
+            float* mine = part + (tt[i] * 2 + h) * ATTN32_PROW;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(mine + dt * 16 + 4 * g) =
+                        make_float4(o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]);
+            *reinterpret_cast<float2*>(mine + 32) = make_float2(ls[0], m[i]);
+        }
+    }
+}
+
+// ... and over a last key tile that holds ONE live key (row 32 t): p = 1 against its own score, so the partial is
+// (V[32 t][:], 1, q . k): four MFMAs for the score, the V row straight from the LDS image.
+__device__ __forceinline__ void attn32_split_one_key(const unsigned char* __restrict__ Ks, const unsigned char* __restrict__ Vs,
+                                                     const bf16x8 (&qf)[4], int t, int lane, float* __restrict__ part) {
+    const int r = lane & 31, h = lane >> 5;
     v16f s;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = 0.0f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + r * 128 + (((2 * ks + h) ^ swz32(r)) << 4));
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + 4096 * t + r * 128 + (((2 * ks + h) ^ swz32(r)) << 4));
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
     }
-    bf16x8 vf[2][2];
+    const float score = __shfl(s[0], 0, 64);  // key 32 t = element 0 of the lanes with h = 0
+    if (r == 0) {
+        float* mine = part + (t * 2 + h) * ATTN32_PROW;
+        const unsigned char* vrow = Vs + 4096 * t;  // row 32 t: swz32 = 0 (32 t is a multiple of 8)
 #pragma unroll
-    for (int kp = 0; kp < 2; ++kp)
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const int row0 = 4 * h + vq, row1 = row0 + 8;
-            const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(
-                vb + 2048 * kp + row0 * 128 + (((4 * dt + vc) ^ swz32(row0)) << 4) + 8 * (vp & 1)));
-            const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(
-                vb + 2048 * kp + row1 * 128 + (((4 * dt + vc) ^ swz32(row1)) << 4) + 8 * (vp & 1)));
-            vf[dt][kp] = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-    const bool ragged = 32 * t + 32 > S;
-    float mx = -INFINITY;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int key = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (!ragged || key < S) mx = fmaxf(mx, s[e]);
+            for (int g = 0; g < 4; ++g) {
+                // O^T rows d = 32 dt + 8 g + 4 h + (0..3)
+                const uint2 w = *reinterpret_cast<const uint2*>(vrow + 2 * (32 * dt + 8 * g + 4 * h));
+                *reinterpret_cast<float4*>(mine + dt * 16 + 4 * g) =
+                    make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                                __uint_as_float(w.y & 0xffff0000u));
+            }
+        *reinterpret_cast<float2*>(mine + 32) = make_float2(1.0f, score);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);                      // finite: every tile that is visited holds a live key
-    const float f = __builtin_amdgcn_exp2f(m_run - m_new);     // 0 for the first tile (m_run = -inf)
-    m_run = m_new;
-    float ls = 0.0f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int key = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
-        float p = __builtin_amdgcn_exp2f(s[e] - m_new);
-        if (ragged) p = key < S ? p : 0.0f;
-        s[e] = p;
-        ls += p;
-    }
-    l = l * f + (ls + __shfl_xor(ls, 32, 64));
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[dt][e] *= f;
-    const bf16x8 p0 = pack8(s, 0), p1 = pack8(s, 8);
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][0], p0, o[dt], 0, 0, 0);
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][1], p1, o[dt], 0, 0, 0);
 }
 
 // exact row maximum of one query tile over the key tiles t0, t0 + tstep, ...: returns -max of this lane's query
@@ -390,15 +444,21 @@ __device__ __forceinline__ void attn32_store(const v16f (&o)[2], float inv, bf16
             const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
             v4u d;
             d.x = rx[0]; d.y = ry[0]; d.z = rx[1]; d.w = ry[1];
+            if (ATTN32_ABL & 128) { asm volatile("" :: "v"(d)); continue; }
+            if (ATTN32_ABL & 512) {
+                const int row0 = qrow - (lane & 31);
+                if (valid) *reinterpret_cast<v4u*>(ctx_b + (size_t)(row0 + 8 * (2 * dt + kk) + (lane >> 3)) * D + 8 * (lane & 7)) = d;
+                continue;
+            }
             if (valid) *reinterpret_cast<v4u*>(ctx_b + (size_t)qrow * D + 32 * dt + 16 * kk + 8 * h) = d;
         }
 }
 
 constexpr float ATTN32_L_LO = 8.271806125530277e-25f;   // 2^-80
 constexpr float ATTN32_L_HI = 1.2676506002282294e30f;   // 2^100
-// LDS behind the two K/V images: the split query's partial sums [2 parities][8 waves][2 lane halves][32 O + l + m] f32,
+// LDS behind the two K/V images: the split query's partials [2 parities][9 key tiles][2 lane halves][ATTN32_PROW] f32,
 // then that query's row of this / the next pair [2][64] bf16
-constexpr int ATTN32_PART = 8 * 2 * 34;
+constexpr int ATTN32_PART = 9 * 2 * ATTN32_PROW;
 constexpr int ATTN32_SCRATCH = 2 * ATTN32_PART * 4 + 2 * 128;
 
 __host__ __device__ constexpr int attn32_lds_bytes(int s_pad) { return 2 * (2 * s_pad * 128) + ATTN32_SCRATCH; }
@@ -409,11 +469,11 @@ __host__ __device__ constexpr int attn32_lds_bytes(int s_pad) { return 2 * (2 * 
 // behind each other in its one vector-memory pipe and every wave stood 3-5 k cycles in the issue, measured) and is
 // waited for (counted vmcnt: the ctx stores stay in flight) only when that compute is done, so the HBM stream of
 // a CU does not stop while its matrix pipe works.
-// Wave w owns query tile w (32 queries).  With S = 257 the ninth tile holds ONE live query (the last token): its
-// key tiles are dealt round-robin to the eight waves, each wave keeps its share exact with its own maximum
-// (online-softmax partials O_w, l_w, m_w), and the eight partials meet in LDS.  They are combined one iteration
-// later, behind the next top-of-loop barrier, so no barrier sits inside an iteration and no wave waits for the
-// slowest one there.  cls_only (last layer): only query 0 is needed: tile 0 alone, whole, by wave 0.
+// Wave w owns query tile w (32 queries).  With S = 257 the ninth tile holds ONE live query (the last token): it is
+// cut by KEY tile into nine partials (O_t, l_t, m_t), each exact against its own tile's maximum and carrying nothing
+// from tile to tile (no running rescale), computed by waves 0-3 (two full tiles each, wave 0 also the one-key tile)
+// and left in LDS.  They are combined one iteration later, behind the next top-of-loop barrier, so no barrier
+// sits inside an iteration and no wave waits for the slowest one there.  cls_only (last layer): only query 0 is needed: tile 0 alone, whole, by wave 0.
 // S_PAD: key rows of one LDS image (multiple of 32, <= 288).  S_CT > 0: compile-time token count.
 #ifdef ATTN32_STAMPS   // tools/probe/attn_bench.hip -DATTN32_STAMPS: per-segment shader cycles of every workgroup (diagnostic build only)
 __device__ unsigned long long* attn32_stamp_buf;
@@ -441,7 +501,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
     // split job: one live query in its tile (S = 32 k + 1: the last token).  cls_only (last layer): only token 0 is
     // needed; its tile is taken WHOLE by wave 0, through the very code path the full layer uses for that tile, so
     // that the CLS-only last layer stays bit-identical to the full one (tests/test_vit_gpu.py)
-    const bool split = !cls_only && nqt == 9 && (S & 31) == 1;
+    const bool split = !(ATTN32_ABL & 32) && !cls_only && nqt == 9 && (S & 31) == 1;
     const int split_row = S - 1;
     const int n_whole = cls_only ? 1 : (split ? 8 : nqt);
 
@@ -477,7 +537,14 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
     };
     auto load_q_raw = [&](bf16x8 (&q)[4], const Pair& pr, int qrow) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) q[ks] = *reinterpret_cast<const bf16x8*>(pr.base + (size_t)qrow * ld + 16 * ks + 8 * h);
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ATTN32_ABL & 256) {
+                const int row0 = qrow - r;  // tile base (the last tile's clamp makes this approximate: timing only)
+                q[ks] = *reinterpret_cast<const bf16x8*>(pr.base + (size_t)max(row0 + 8 * ks + (lane >> 3), 0) * ld + 8 * (lane & 7));
+                continue;
+            }
+            q[ks] = *reinterpret_cast<const bf16x8*>(pr.base + (size_t)qrow * ld + 16 * ks + 8 * h);
+        }
     };
     auto scale_q = [&](bf16x8 (&q)[4]) {
         if constexpr (!PRESCALED) {
@@ -492,17 +559,17 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
     // the split query's partials of one pair -> its ctx row (wave 1, one iteration later)
     auto combine = [&](const float* part, bf16_t* ctx_prev) {
         float M = -INFINITY;
-        for (int w = 0; w < 8; ++w) M = fmaxf(M, part[(w * 2) * 34 + 33]);
-        float lt = 0.0f, wgt[8];
-        for (int w = 0; w < 8; ++w) {
-            const float mw = part[(w * 2) * 34 + 33];
-            wgt[w] = mw == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(mw - M);
-            lt += wgt[w] * part[(w * 2) * 34 + 32];  // the row sum is complete in either lane half
+        for (int t = 0; t < 9; ++t) M = fmaxf(M, part[(t * 2) * ATTN32_PROW + 33]);
+        float lt = 0.0f, wgt[9];
+        for (int t = 0; t < 9; ++t) {
+            const float mt = part[(t * 2) * ATTN32_PROW + 33];
+            wgt[t] = mt == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(mt - M);
+            lt += wgt[t] * part[(t * 2) * ATTN32_PROW + 32];  // the row sum is complete in either lane half
         }
         // lane = output column d: O^T row d = 32 dt + (reg & 3) + 8 (reg >> 2) + 4 h
         const int dt = lane >> 5, w32 = lane & 31, hh = (w32 >> 2) & 1, reg = (w32 & 3) + 4 * (w32 >> 3);
         float acc = 0.0f;
-        for (int w = 0; w < 8; ++w) acc += wgt[w] * part[(w * 2 + hh) * 34 + dt * 16 + reg];
+        for (int t = 0; t < 9; ++t) acc += wgt[t] * part[(t * 2 + hh) * ATTN32_PROW + dt * 16 + reg];
         ctx_prev[(size_t)split_row * D + lane] = f2bf(acc / lt);
     };
 
@@ -530,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         // this pair's K, V and queries have landed once every wave has waited for its own loads: younger than
         // them are only the ctx stores of the previous iteration (4 per wave that owns a full tile), which stay in flight
         // (raw s_barrier: __syncthreads() would add vmcnt(0) and drain the stores and, further down, the next pair's DMA)
-        if (it == 0 || !four_stores) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (it == 0 || !four_stores || (ATTN32_ABL & 128)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         ATTN32_STAMP(0)   // own DMA / loads landed
         ATTN32_BARRIER
@@ -551,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         // pieces wave, wave + 8, ... go out one per key-tile step of the sweep below, the rest right after it
         int piece = wave;
         auto dma_hook = [&] {
-            if (more && piece < NPIECE) dma_piece(nxt, b ^ 1, piece);
+            if (more && piece < NPIECE && !(ATTN32_ABL & 64)) dma_piece(nxt, b ^ 1, piece);
             piece += 8;
         };
         if (split && it > 0 && wave == 1) combine(scratch + (b ^ 1) * ATTN32_PART, ctx_prev);  // the previous pair's split query
@@ -565,6 +632,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         };
         // ---- whole tiles: tile w, w + 8, ... of this wave
         for (int qt = wave; qt < n_whole; qt += 8) {
+            if ((ATTN32_ABL & 16) && wave >= 4) break;
             if (qt != wave) {  // only when S > 256 without the split (generic shapes): fetch that tile's queries now
                 load_q_raw(qa, cur, min(32 * qt + r, S - 1));
                 scale_q(qa);
@@ -595,21 +663,12 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
             for (int ks = 0; ks < 4; ++ks) qb[ks] = *reinterpret_cast<const bf16x8*>(qsplit + b * 128 + 32 * ks + 16 * h);
             scale_q(qb);
             if (qs_lane) *reinterpret_cast<v4u*>(qsplit + (b ^ 1) * 128 + 16 * lane) = qs_n;  // next pair's row, read behind the next barrier
-            clear();
-            float l = 0.0f, m_run = -INFINITY;
-            // shares: key tiles w, w + 4, ... of waves 0-3 only — the first-dispatched wave of each SIMD wins the issue
-            // arbitration and finishes its whole tile ~1/3 earlier (measured 6.4 k vs 9.5 k cycles); this fills its wait
-            const int nkt = (S + 31) >> 5;
-            if (wave < 4)
-                for (int t = wave; t < nkt; t += 4) attn32_tile_online<S_CT>(Ks, Vs, qb, S_rt, t, lane, o, l, m_run);
-            if (r == 0) {
-                float* mine = scratch + b * ATTN32_PART + (wave * 2 + h) * 34;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) mine[dt * 16 + e] = o[dt][e];
-                mine[32] = l;
-                mine[33] = m_run;
+            // one partial per key tile, all by waves 0-3: the first-dispatched wave of each SIMD wins the issue arbitration
+            // and finishes its whole tile ~1/3 earlier than its partner (measured 6.7 k vs 10 k cycles); this fills its wait
+            if (wave < 4) {
+                float* part = scratch + b * ATTN32_PART;
+                attn32_split_tiles(Ks, Vs, qb, wave, wave + 4, lane, part);
+                if (wave == 0) attn32_split_one_key(Ks, Vs, qb, 8, lane, part);
             }
             ctx_prev = cur.ctx_b;
         }
