@@ -64,6 +64,9 @@ constexpr float ATTN32_C2 = 0.125f * 1.4426950408889634f;  // scale * log2(e)
 #ifndef ATTN32_ABL
 #define ATTN32_ABL 0
 #endif
+#ifndef ATTN32_QSPREAD
+#define ATTN32_QSPREAD 1  // the next pair's query fragments: one load per key step (1) or all four behind the barrier (0)
+#endif
 
 // One query tile swept over the key tiles t0, t0 + tstep, ... < nkt, software-pipelined: the scores of
 // the NEXT key tile (4 MFMAs) are issued between the four slices of the current tile's numerators
@@ -227,7 +230,7 @@ __device__ __forceinline__ void attn32_sweep_static(const unsigned char* __restr
         const bool one_key = last && ONE_KEY;
         const bool ragged = last && (S_CT % 32) != 0;
         bf16x8 (&kn)[4] = kf[(ATTN32_ABL & 4) ? 0 : (t + 1) & 1];  // tile t + 1, read during step t - 1
-        hook();  // the caller's per-step work (one piece of the next pair's LDS-DMA)
+        hook(t);  // the caller's per-step work (one piece of the next pair's LDS-DMA, one of its query loads)
         // this step's V fragments (used by its last MFMAs) and the K fragments of the step after next, up front
         if (!(ATTN32_ABL & 4) || t == 0)
 #pragma unroll
@@ -609,10 +612,13 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         const int next = pair + G;
         const bool more = next < n_pairs;
         const Pair nxt = pair_of(more ? next : pair);
+        // this wave's next query fragments: behind the barrier, or (static sweep) one per key step behind its DMA pieces
+        constexpr int Q0 = (S_CT + 31) / 32 - 4;  // the last four key steps of the static sweep carry them
+        const bool q_at_top = !ATTN32_QSPREAD || S_CT == 0 || Q0 < 0 || force_shift != 0 || wave >= n_whole;
         if (more) {
             // ordinary loads first: a later wait for them must not have to wait for the DMA behind them
             if (qs_lane) qs_n = *reinterpret_cast<const v4u*>(nxt.base + (size_t)split_row * ld + 8 * lane);
-            load_q_raw(qa_n, nxt, my_row);
+            if (q_at_top) load_q_raw(qa_n, nxt, my_row);
         }
         // the other K/V image is free (every wave passed the barrier above after its last read of it): the next pair's
         // pieces wave, wave + 8, ... go out one per key-tile step of the sweep below, the rest right after it
@@ -620,6 +626,13 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         auto dma_hook = [&] {
             if (more && piece < NPIECE && !(ATTN32_ABL & 64)) dma_piece(nxt, b ^ 1, piece);
             piece += 8;
+        };
+        // (all eight waves issuing their four 32-line query loads at once right behind the barrier cost the younger wave
+        // of a SIMD ~1 k cycles there; step is a compile-time constant in the unrolled sweep: qa_n stays in registers)
+        auto dma_q_hook = [&](int step) {
+            dma_hook();
+            if (more && !q_at_top && step >= Q0 && step < Q0 + 4)
+                qa_n[step - Q0] = *reinterpret_cast<const bf16x8*>(nxt.base + (size_t)my_row * ld + 16 * (step - Q0) + 8 * h);
         };
         if (split && it > 0 && wave == 1) combine(scratch + (b ^ 1) * ATTN32_PART, ctx_prev);  // the previous pair's split query
         ATTN32_STAMP(2)
@@ -641,9 +654,9 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
             float l = 0.0f;
             bool shifted = force_shift != 0;
             if (!shifted) {
-                if constexpr (S_CT > 0) attn32_sweep_static<S_CT, false>(Ks, Vs, qa, 0.0f, lane, o, l, dma_hook);
+                if constexpr (S_CT > 0) attn32_sweep_static<S_CT, false>(Ks, Vs, qa, 0.0f, lane, o, l, dma_q_hook);
                 else attn32_sweep<S_CT, false>(Ks, Vs, qa, 0.0f, S_rt, 0, 1, lane, o, l, dma_hook);
-                shifted = __any(!(l > ATTN32_L_LO && l < ATTN32_L_HI));
+                shifted = !ATTN32_ABL && __any(!(l > ATTN32_L_LO && l < ATTN32_L_HI));  // (ablation builds compute garbage: no second pass for it)
             }
             if (shifted) {  // rare: a numerator left the exponent range (or the caller asked for the shifted pass)
                 clear();

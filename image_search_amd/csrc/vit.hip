@@ -152,7 +152,7 @@ void load_weights(mi_clip* m, const char* path) {
         for (int d = 0; d < D; ++d) std::memcpy(&wp[(size_t)d * m->Kp], &w[(size_t)d * K], (size_t)K * 4);
         m->wpatch = upload_mat(m, wp);
     }
-    m->q_prescaled = m->precision == MI_PRECISION_BF16 && m->attn_ver == 2 && m->S > 64 && m->S <= 288;
+    m->q_prescaled = m->precision == MI_PRECISION_BF16 && m->attn_ver >= 2 && m->S > 64 && m->S <= 288;
     load_layers(m, st, v);
 }
 
@@ -339,7 +339,7 @@ void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, 
         const int qb = first_tile_only ? 1 : (m->S + 63) / 64;
         const unsigned blocks = (unsigned)(n * m->H * qb);
         hipLaunchKernelGGL(attn_f32_kernel, dim3(blocks), dim3(64), 0, s, (const float*)qkv, (float*)ctx, m->S, m->D, m->H, m->text ? 1 : 0, first_tile_only ? 1 : 0);
-    } else if (m->attn_ver == 2 && !m->text && m->S > 64 && m->S <= 288) {
+    } else if (m->attn_ver >= 2 && !m->text && m->S > 64 && m->S <= 288) {
 #define MI_ATTN32(SP, SC)                                                                                              \
     {                                                                                                                  \
         constexpr int LDS = attn32_lds_bytes(SP);                                                                      \
