@@ -138,7 +138,7 @@ void load_weights(mi_clip* m, const char* path) {
     const int K = 3 * m->patch * m->patch;
     m->Kp = (K + 63) / 64 * 64;
 
-    const int D = m->D, FF = m->FF;
+    const int D = m->D;
     m->cls = upload_f32(m, st.read(v + "embeddings.class_embedding", D));
     m->pos = upload_f32(m, st.read(v + "embeddings.position_embedding.weight", (int64_t)m->S * D));
     m->pre_w = upload_f32(m, st.read(v + "pre_layrnorm.weight", D));
@@ -152,7 +152,7 @@ void load_weights(mi_clip* m, const char* path) {
         for (int d = 0; d < D; ++d) std::memcpy(&wp[(size_t)d * m->Kp], &w[(size_t)d * K], (size_t)K * 4);
         m->wpatch = upload_mat(m, wp);
     }
-    m->q_prescaled = m->precision == MI_PRECISION_BF16 && m->attn_ver >= 2 && m->S > 64 && m->S <= 288;
+    m->q_prescaled = m->precision == MI_PRECISION_BF16 && m->attn_ver == 2 && m->S > 64 && m->S <= 288;
     load_layers(m, st, v);
 }
 
