@@ -126,6 +126,88 @@ class EmbeddingTable {
         check(mi_knn_search(h_, reference.data(), 1, k, idx.data(), dist.data()));
         return {idx, dist};
     }
+    mi_knn* handle() const { return h_; }
+};
+
+// the whole table `image` {id, image_path, embedding} (server/src/search.rs:13-18) and the four statements the
+// server issues against it
+class ImageIndex {
+    mi_index* h_ = nullptr;
+    static std::vector<const char*> ptrs(const std::vector<std::string>& v) {
+        std::vector<const char*> p;
+        for (const auto& s : v) p.push_back(s.c_str());
+        return p;
+    }
+
+   public:
+    explicit ImageIndex(uint32_t dim = 768, int device = 0, const std::string& media_dir = "") {
+        check(mi_index_create(dim, device, media_dir.c_str(), &h_));
+    }
+    ImageIndex(const ImageIndex&) = delete;
+    ~ImageIndex() { mi_index_free(h_); }
+    mi_index* handle() const { return h_; }
+    uint64_t size() const { uint64_t n = 0; check(mi_index_size(h_, &n)); return n; }
+    // SELECT image_path FROM image WHERE image_path IN $paths  (server/src/clip.rs:74-83)
+    std::vector<bool> existing(const std::vector<std::string>& paths) const {
+        std::vector<uint8_t> e(paths.size());
+        const auto p = ptrs(paths);
+        check(mi_index_existing(h_, p.data(), p.size(), e.data()));
+        return std::vector<bool>(e.begin(), e.end());
+    }
+    // db.insert("image").content(rows)  (server/src/clip.rs:125-137): returns the id of the first row
+    uint64_t insert(const std::vector<std::string>& paths, const std::vector<float>& embeddings) {
+        uint64_t first = 0;
+        const auto p = ptrs(paths);
+        check(mi_index_insert(h_, p.data(), embeddings.data(), p.size(), &first));
+        return first;
+    }
+    std::string path(uint64_t id, bool web = false) const {
+        size_t need = 0;
+        check(mi_index_path(h_, id, web ? 1 : 0, nullptr, 0, &need));
+        std::string s(need - 1, '\0');  // `needed` counts the terminating NUL
+        check(mi_index_path(h_, id, web ? 1 : 0, &s[0], need, &need));
+        return s;
+    }
+    // web_search_text behind the text embedding (server/src/search.rs:43-110): refine with the referenced images'
+    // stored embeddings, then `embedding <|k|> $reference`; (id, distance) ascending, missing results dropped
+    std::vector<std::pair<uint64_t, float>> search(const std::vector<float>& text_embedding, const std::vector<std::string>& referenced_images,
+                                                   uint32_t k = 1000) const {
+        std::vector<uint64_t> idx(k);
+        std::vector<float> dist(k);
+        uint32_t n = 0;
+        const auto p = ptrs(referenced_images);
+        check(mi_index_search(h_, text_embedding.data(), p.data(), p.size(), k, idx.data(), dist.data(), &n));
+        std::vector<std::pair<uint64_t, float>> out;
+        for (uint32_t i = 0; i < n; ++i) out.emplace_back(idx[i], dist[i]);
+        return out;
+    }
+    void save(const std::string& dir) const { check(mi_index_save(h_, dir.c_str())); }
+    void load(const std::string& dir) { check(mi_index_load(h_, dir.c_str())); }
+};
+
+// the table row-sharded over several GPUs of ONE process: same results as one EmbeddingTable
+class ShardedTable {
+    mi_knn_sharded* h_ = nullptr;
+    uint32_t dim_;
+
+   public:
+    ShardedTable(uint32_t dim, const std::vector<int>& devices, uint32_t block_rows = 0) : dim_(dim) {
+        check(mi_knn_sharded_create(dim, devices.data(), (int)devices.size(), block_rows, &h_));
+    }
+    ShardedTable(const ShardedTable&) = delete;
+    ~ShardedTable() { mi_knn_sharded_free(h_); }
+    uint64_t insert(const std::vector<float>& rows) {
+        uint64_t first = 0;
+        check(mi_knn_sharded_append(h_, rows.data(), rows.size() / dim_, &first));
+        return first;
+    }
+    uint64_t size() const { uint64_t n = 0; check(mi_knn_sharded_info(h_, &n, nullptr, nullptr, nullptr)); return n; }
+    std::pair<std::vector<uint64_t>, std::vector<float>> knn(const std::vector<float>& reference, uint32_t k = 1000) const {
+        std::vector<uint64_t> idx(k);
+        std::vector<float> dist(k);
+        check(mi_knn_sharded_search(h_, reference.data(), 1, k, idx.data(), dist.data()));
+        return {idx, dist};
+    }
 };
 
 }  // namespace image_search

@@ -50,6 +50,27 @@ int main(int argc, char** argv) {
         EXPECT(res.first[0] == 3);
         EXPECT(res.first[5] == MI_KNN_NO_ID && std::isinf(res.second[6]));
         for (int i = 1; i < 5; ++i) EXPECT(res.second[i] >= res.second[i - 1]);
+        // the table with its path column: the reference's four statements
+        ImageIndex ix(768, 0, "/srv/media/");
+        const std::vector<std::string> paths{"/srv/media/a.jpg", "/srv/media/sub/b.png", "/srv/media/c.jpg", "/srv/media/d.jpg", "/srv/media/e.jpg"};
+        EXPECT(ix.insert(paths, rows) == 0 && ix.size() == 5);
+        const auto ex = ix.existing({"/srv/media/c.jpg", "/srv/media/zzz.jpg"});
+        EXPECT(ex[0] && !ex[1]);
+        EXPECT(ix.path(1) == "/srv/media/sub/b.png" && ix.path(1, true) == "media/sub/b.png");
+        const auto hits = ix.search(q, {}, 1000);          // fewer rows than K: five results, nearest first
+        EXPECT(hits.size() == 5 && hits[0].first == 3);
+        const auto refined = ix.search(q, {"/srv/media/a.jpg"}, 2);   // reference = mean(mean(selected), text): rows 0 and 3 lead
+        EXPECT(refined.size() == 2 && ((refined[0].first == 0 && refined[1].first == 3) || (refined[0].first == 3 && refined[1].first == 0)));
+        // three shards on one device (64-row blocks dealt round-robin) give what the single table gives, bit for bit
+        std::vector<float> many(200 * 768, 0.0f);
+        for (int r = 0; r < 200; ++r) { many[r * 768 + r] = 1.0f; many[r * 768 + 300] = 0.01f * r; many[r * 768 + 3] += 0.001f * (r % 7); }
+        EmbeddingTable one(768, 0);
+        one.insert(many);
+        ShardedTable st(768, {0, 0, 0}, 64);
+        EXPECT(st.insert(many) == 0 && st.size() == 200);
+        const auto a = one.knn(q, 50), b = st.knn(q, 50);
+        EXPECT(a.first == b.first);
+        EXPECT(std::memcmp(a.second.data(), b.second.data(), 50 * sizeof(float)) == 0);
     } else if (mi_device_count() == 0) {
         bool threw = false;
         try { EmbeddingTable t(768, 0); } catch (const std::runtime_error& e) { threw = std::strstr(e.what(), "no CPU fallback") != nullptr; }
