@@ -40,6 +40,8 @@ SYMBOLS = {
     "mi_knn_create": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "mi_knn_free": (None, [c_vp]),
     "mi_knn_set_base": (ctypes.c_int, [c_vp, ctypes.c_uint64]),
+    "mi_knn_set_option": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
+    "mi_knn_prefilter_stats": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "mi_knn_reserve": (ctypes.c_int, [c_vp, ctypes.c_uint64]),
     "mi_knn_size": (ctypes.c_int, [c_vp, c_u64p]),
     "mi_knn_append": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint64]),

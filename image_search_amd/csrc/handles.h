@@ -95,6 +95,17 @@ struct mi_knn {
     uint32_t* d_keys32 = nullptr;  // one distance key per row (selection path, 64 < k <= 4096)
     uint32_t* d_sel = nullptr;     // 6 x 2048 histogram bins + the collect counter
     size_t keys32_cap = 0, sel_cap = 0;
+    // two-stage exact search (mi_knn_set_option "prefilter"): a bf16 copy of the rows + their squared norms, kept up to
+    // `mirror_rows` and caught up by the next search; candidate rows / keys of stage 2
+    bool prefilter = false;
+    bool last_prefiltered = false;  // the most recent single-query search went through the two stages
+    uint16_t* d_mirror = nullptr;
+    float* d_xx = nullptr;
+    uint64_t mirror_rows = 0;
+    size_t mirror_cap = 0, xx_cap = 0;
+    uint32_t* d_pref_rows = nullptr;
+    uint64_t* d_pref_keys = nullptr;   // [2 * PREF_CAP]: candidates' keys, then the k best
+    size_t pref_rows_cap = 0, pref_keys_cap = 0;
     // Order across caller streams.  `writes`: the last append (a search must see every row counted in
     // `rows`).  `reads`: the last search (searches share the workspace above, and a reallocation of the
     // table must wait for them).  An append only ever writes rows beyond `rows`, so it does not wait

@@ -299,7 +299,10 @@ int mi_index_load(mi_index* ix, const char* dir) {
         // the embedding file is written first: it may be NEWER than the path file (a crash between the two renames);
         // rows without a path cannot be served and are not kept.  The other way round cannot happen.
         if (rows < paths.size()) fail(MI_ERR_IO, "%s: %llu embeddings for %zu paths", dir, (unsigned long long)rows, paths.size());
-        if (rows > paths.size()) ix->table->rows = paths.size();
+        if (rows > paths.size()) {
+            ix->table->rows = paths.size();
+            ix->table->mirror_rows = std::min<uint64_t>(ix->table->mirror_rows, paths.size());  // (rows beyond are rewritten by later inserts)
+        }
         ix->media_dir = media;
         for (const auto& p : paths) add_path(ix, p);
     });

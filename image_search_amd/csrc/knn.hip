@@ -68,14 +68,14 @@ void allow_lds(K kernel, size_t bytes) {
 
 template <class Top>
 void launch_scan(mi_knn* t, const float* d_q, uint32_t k, const uint64_t* lo, uint64_t* cand, uint32_t blocks,
-                 hipStream_t s) {
+                 hipStream_t s, const uint32_t* run_if = nullptr) {
     const size_t lds = (size_t)4 * Top::LDS_KEYS * sizeof(uint64_t);
     switch (t->dim / 64) {
 #define MI_CASE(NCH)                                                                                   \
     case NCH:                                                                                          \
         allow_lds(knn_scan_kernel<NCH, Top>, lds);                                                     \
         hipLaunchKernelGGL((knn_scan_kernel<NCH, Top>), dim3(blocks), dim3(256), lds, s, t->table,     \
-                           t->rows, d_q, k, lo, cand);                                                 \
+                           t->rows, d_q, k, lo, cand, (uint32_t*)nullptr, run_if);                     \
         break;
         MI_CASE(1) MI_CASE(2) MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16)
 #undef MI_CASE
@@ -86,25 +86,26 @@ void launch_scan(mi_knn* t, const float* d_q, uint32_t k, const uint64_t* lo, ui
 
 template <class Top>
 void launch_merge(const uint64_t* in, uint32_t n_lists, uint32_t k, uint32_t lpb, uint64_t* out, uint32_t nq,
-                  size_t in_stride, size_t out_stride, hipStream_t s) {
+                  size_t in_stride, size_t out_stride, hipStream_t s, const uint32_t* run_if = nullptr) {
     const size_t lds = (size_t)4 * Top::LDS_KEYS * sizeof(uint64_t);
     allow_lds(knn_merge_kernel<Top>, lds + 4096);
     const uint32_t blocks = (n_lists + lpb - 1) / lpb;
     hipLaunchKernelGGL((knn_merge_kernel<Top>), dim3(blocks, nq), dim3(256), lds, s, in, n_lists, k, lpb, out,
-                       in_stride, out_stride);
+                       in_stride, out_stride, run_if);
     HIP_CHECK(hipGetLastError());
 }
 
 // One pass: the kp <= 1024 smallest keys (> *lo if lo) of the shard, ascending, into keys_out[0..kp).
 template <class Top>
-void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint64_t* keys_out, hipStream_t s) {
+void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint64_t* keys_out, hipStream_t s,
+              const uint32_t* run_if = nullptr) {
     const uint32_t bpc = Top::LDS_KEYS == 0 ? 4 : (Top::KP <= 256 ? 4 : 2);
     const uint64_t n_tiles = (t->rows + 63) / 64;
     uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * bpc, (n_tiles + 3) / 4);
     blocks = std::max(blocks, 1u);
     const uint32_t lists = blocks * 4;
     ensure(t, (void**)&t->d_cand, &t->cand_keys, (size_t)lists * kp, sizeof(uint64_t));
-    launch_scan<Top>(t, d_q, kp, lo, t->d_cand, blocks, s);
+    launch_scan<Top>(t, d_q, kp, lo, t->d_cand, blocks, s, run_if);
     if constexpr (Top::LDS_KEYS != 0) {
         // k > 64: block-cooperative tree, 16 lists per block per level, ping-pong between d_tmp halves
         constexpr uint32_t LPB = 16;
@@ -123,13 +124,65 @@ void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint
     }
     // tree: <= 64 lists per block, then one block
     if (lists <= 64) {
-        launch_merge<Top>(t->d_cand, lists, kp, lists, keys_out, 1, 0, 0, s);
+        launch_merge<Top>(t->d_cand, lists, kp, lists, keys_out, 1, 0, 0, s, run_if);
     } else {
         const uint32_t lpb = 32, mid = (lists + lpb - 1) / lpb;
         ensure(t, (void**)&t->d_tmp, &t->tmp_keys, (size_t)mid * kp, sizeof(uint64_t));
-        launch_merge<Top>(t->d_cand, lists, kp, lpb, t->d_tmp, 1, 0, 0, s);
-        launch_merge<Top>(t->d_tmp, mid, kp, mid, keys_out, 1, 0, 0, s);
+        launch_merge<Top>(t->d_cand, lists, kp, lpb, t->d_tmp, 1, 0, 0, s, run_if);
+        launch_merge<Top>(t->d_tmp, mid, kp, mid, keys_out, 1, 0, 0, s, run_if);
     }
+}
+
+// Two-stage exact search (knn_kernels.h "bf16 mirror as prefilter"): k <= 64, dim a multiple of 128, enough rows for the
+// saved bytes to outweigh ten short launches.  Leaves the answer's keys in d_pref_keys[PREF_CAP ..] and *fallback == 0,
+// or *fallback == 1: the caller enqueues the single-pass scan behind it, gated by that word.
+constexpr uint64_t PREF_MIN_ROWS = 1u << 18;
+bool prefilter_applies(const mi_knn* t, uint32_t k) {
+    return t->prefilter && k <= 64 && t->dim % 128 == 0 && t->rows >= PREF_MIN_ROWS;
+}
+uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s) {
+    ensure(t, (void**)&t->d_keys32, &t->keys32_cap, (size_t)t->cap, sizeof(uint32_t));
+    ensure(t, (void**)&t->d_sel, &t->sel_cap, (size_t)6 * SEL_BINS + 64, sizeof(uint32_t));
+    ensure(t, (void**)&t->d_pref_rows, &t->pref_rows_cap, (size_t)PREF_CAP, sizeof(uint32_t));
+    ensure(t, (void**)&t->d_pref_keys, &t->pref_keys_cap, (size_t)2 * PREF_CAP, sizeof(uint64_t));
+    if (t->mirror_cap < (size_t)t->cap * t->dim || t->xx_cap < (size_t)t->cap) t->mirror_rows = 0;  // (re)allocated below: rebuild
+    t->mirror_rows = std::min(t->mirror_rows, t->rows);
+    ensure(t, (void**)&t->d_mirror, &t->mirror_cap, (size_t)t->cap * t->dim, sizeof(uint16_t));
+    ensure(t, (void**)&t->d_xx, &t->xx_cap, (size_t)t->cap, sizeof(float));
+    const uint64_t n_tiles = (t->rows + 63) / 64;
+    const uint32_t blocks = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 4, (n_tiles + 3) / 4));
+    const uint32_t hb = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 8, (t->rows + 255) / 256);
+    uint32_t* count = t->d_sel + 6 * SEL_BINS;
+    uint32_t* fallback = count + 1;
+    SelState* states = reinterpret_cast<SelState*>(t->d_sel + 6 * SEL_BINS + 4);
+    HIP_CHECK(hipMemsetAsync(t->d_sel, 0, ((size_t)6 * SEL_BINS + 64) * sizeof(uint32_t), s));
+    const float eps = 0x1p-9f + 4.1f * (float)(t->dim + 8) * 0x1p-24f + 2e-6f;
+    switch (t->dim / 64) {
+#define MI_CASE(NCH)                                                                                                     \
+    case NCH:                                                                                                            \
+        if (t->mirror_rows < t->rows) {                                                                                  \
+            const uint64_t todo = t->rows - t->mirror_rows;                                                              \
+            const uint32_t mb = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 8, (todo + 15) / 16);                   \
+            hipLaunchKernelGGL((knn_mirror_kernel<NCH>), dim3(std::max(mb, 1u)), dim3(256), 0, s, t->table, t->mirror_rows, \
+                               t->rows, t->d_mirror, t->d_xx);                                                           \
+            t->mirror_rows = t->rows;                                                                                    \
+        }                                                                                                                \
+        hipLaunchKernelGGL((knn_scan_coarse_kernel<NCH>), dim3(blocks), dim3(256), 0, s, t->d_mirror, t->d_xx, t->rows,  \
+                           d_q, t->d_keys32);                                                                            \
+        for (int p = 0; p < 3; ++p)                                                                                      \
+            hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, p, t->d_sel, states); \
+        hipLaunchKernelGGL(knn_prefilter_collect_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, t->d_sel,   \
+                           states, 2.0f * eps, PREF_CAP, t->d_pref_rows, count);                                         \
+        hipLaunchKernelGGL((knn_rescore_kernel<NCH>), dim3(PREF_CAP / 16), dim3(256), 0, s, t->table, d_q, t->d_pref_rows, \
+                           count, PREF_CAP, t->d_pref_keys, fallback);                                                   \
+        break;
+        MI_CASE(2) MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16)
+#undef MI_CASE
+        default: fail(MI_ERR_UNSUPPORTED, "dim %u: the prefilter is built for dim/64 in {2,4,8,12,16}", t->dim);
+    }
+    hipLaunchKernelGGL(knn_topk_sort_kernel, dim3(1), dim3(1024), 0, s, t->d_pref_keys, count, fallback, k, t->d_pref_keys + PREF_CAP);
+    HIP_CHECK(hipGetLastError());
+    return fallback;
 }
 
 // 64 < k <= 4096: every row's distance key, then the k smallest (distance, id) keys by radix select (knn_kernels.h)
@@ -175,6 +228,15 @@ void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float*
         select_pass(t, d_q, k, t->d_keys, s);
         hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, id_map(t),
                            d_idx, d_dist, (size_t)0, (size_t)0);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    t->last_prefiltered = prefilter_applies(t, k);
+    if (t->last_prefiltered) {
+        const uint32_t* fallback = prefilter_pass(t, d_q, k, s);
+        one_pass<WaveTopReg>(t, d_q, k, nullptr, t->d_keys, s, fallback);  // returns at once unless *fallback
+        hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, id_map(t),
+                           d_idx, d_dist, (size_t)0, (size_t)0, t->d_pref_keys + PREF_CAP, fallback);
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -272,9 +334,47 @@ void mi_knn_free(mi_knn* t) {
     t->reads.destroy();
     if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
     for (void* p : {(void*)t->table, (void*)t->d_q, (void*)t->d_cand, (void*)t->d_tmp, (void*)t->d_keys,
-                    (void*)t->d_idx, (void*)t->d_dist, (void*)t->d_keys32, (void*)t->d_sel})
+                    (void*)t->d_idx, (void*)t->d_dist, (void*)t->d_keys32, (void*)t->d_sel, (void*)t->d_mirror,
+                    (void*)t->d_xx, (void*)t->d_pref_rows, (void*)t->d_pref_keys})
         if (p) (void)hipFree(p);
     delete t;
+}
+
+int mi_knn_set_option(mi_knn* t, const char* key, int value) {
+    return guarded([&] {
+        if (!t || !key) fail(MI_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> l(t->mu);
+        const std::string k(key);
+        if (k == "prefilter") {
+            // two-stage exact search for k <= 64: a bf16 mirror of the rows (+ 50 % memory, built by the next search and
+            // kept up to date by every later one) prefilters, the fp32 rows decide; results are those of the single pass
+            if (value != 0 && value != 1) fail(MI_ERR_INVALID, "prefilter: 0 or 1 (got %d)", value);
+            t->prefilter = value != 0;
+            if (!t->prefilter && t->d_mirror) {
+                DeviceGuard g(t->device);
+                t->reads.sync();
+                HIP_CHECK(hipFree(t->d_mirror)); t->d_mirror = nullptr; t->mirror_cap = 0;
+                HIP_CHECK(hipFree(t->d_xx)); t->d_xx = nullptr; t->xx_cap = 0;
+                t->mirror_rows = 0;
+            }
+        } else {
+            fail(MI_ERR_INVALID, "unknown option '%s' (known: prefilter)", key);
+        }
+    });
+}
+
+int mi_knn_prefilter_stats(mi_knn* t, uint32_t* candidates, uint32_t* fell_back) {
+    return guarded([&] {
+        if (!t || !candidates || !fell_back) fail(MI_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> l(t->mu);
+        *candidates = 0; *fell_back = 0;
+        if (!t->last_prefiltered) return;
+        DeviceGuard g(t->device);
+        t->reads.sync();
+        uint32_t w[2] = {0, 0};
+        HIP_CHECK(hipMemcpy(w, t->d_sel + 6 * SEL_BINS, sizeof w, hipMemcpyDeviceToHost));
+        *candidates = w[0]; *fell_back = w[1];
+    });
 }
 
 int mi_knn_set_base(mi_knn* t, uint64_t base) {

@@ -37,6 +37,7 @@
 namespace mi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint64_t KEY_MAX = 0xFFFFFFFFFFFFFFFFull;
 
@@ -218,9 +219,11 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const float* __restric
                                                        const float* __restrict__ q, uint32_t k,
                                                        const uint64_t* __restrict__ lo_ptr,
                                                        uint64_t* __restrict__ cand,
-                                                       uint32_t* __restrict__ all_keys = nullptr) {
+                                                       uint32_t* __restrict__ all_keys = nullptr,
+                                                       const uint32_t* __restrict__ run_if = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int DIM = NCH * 64;
+    if (run_if && *run_if == 0u) return;  // the fallback behind a prefilter that did not need it
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
     const uint32_t wave = blockIdx.x * 4 + wib, n_waves = gridDim.x * 4;
@@ -433,6 +436,205 @@ __global__ __launch_bounds__(1024) void knn_select_sort_kernel(const uint64_t* _
     for (uint32_t j = threadIdx.x; j < k; j += 1024) out[j] = buf[j];
 }
 
+// ---- two-stage EXACT search: a bf16 mirror as prefilter (opt-in, k <= 64) ----------------------------------------
+// The scan above is bound by the bytes of the table; 288 GB of HBM per GPU leave room to keep the rows a second time
+// at half the width.  Stage 1 scans the bf16 mirror (dim*2 bytes per row + a stored f32 norm) and writes every row's
+// COARSE distance key; the k-th smallest coarse distance t is found by the radix select's three distance passes;
+// every row with coarse distance <= t + 2 eps becomes a candidate; stage 2 evaluates the candidates from the fp32
+// table with the arithmetic of knn_scan_kernel, bit for bit, and the k smallest of THOSE keys are the answer.
+//
+// Why it is exact.  With eps >= |coarse - exact| for every row: the k rows of smallest coarse distance have exact
+// distances <= t + eps, so the exact k-th distance is <= t + eps, so every row of the exact answer has coarse distance
+// <= t + 2 eps and is a candidate.  The bound: x~ = bf16(x) rounds to nearest, |x~_j - x_j| <= 2^-9 |x_j|, hence
+// |q.x~ - q.x| <= 2^-9 sum|q_j x_j| <= 2^-9 |q| |x| (Cauchy-Schwarz), i.e. 2^-9 on the cosine; the fp32 summations of
+// both sides (any order) add <= 2 gamma_n each with gamma_n = (n + 8) 2^-24, the norms (stored vs recomputed) another
+// 2 gamma_n, the divisions / square roots / subtraction a few ulp of O(1):  eps = 2^-9 + 4.1 (dim + 8) 2^-24 + 2e-6
+// (2.14e-3 at dim 768), independent of the data.  Rows the bound does not cover (a non-finite or > 3e38 element, a
+// squared norm outside [1e-30, 1e30]) are marked in the mirror and are always candidates.  More candidates than the
+// buffer holds (adversarial corpora: everything within 2 eps of the k-th) => the single-pass scan runs instead; it is
+// enqueued behind stage 2 either way and returns at once when it is not needed (no host round trip).
+constexpr uint32_t PREF_CAP = 4096;  // candidates stage 2 accepts (one block sorts their keys)
+
+// rows [first, end) of the table -> bf16 mirror rows + stored squared norms (-1 = "always a candidate")
+template <int NCH>
+__global__ __launch_bounds__(256) void knn_mirror_kernel(const float* __restrict__ table, uint64_t first, uint64_t end,
+                                                         uint16_t* __restrict__ mirror, float* __restrict__ xx) {
+    constexpr int DIM = NCH * 64;
+    const int lane = threadIdx.x & 63, i = lane & 15;
+    const uint64_t group = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4, n_groups = ((uint64_t)gridDim.x * 256) >> 4;
+    for (uint64_t r0 = first + group; r0 < ((end - first + n_groups - 1) / n_groups) * n_groups + first; r0 += n_groups) {
+        const bool live = r0 < end;  // (whole 16-lane groups stay in the loop: row16_sum is a cross-lane operation)
+        const uint64_t r = live ? r0 : end - 1;
+        const f32x4* p = reinterpret_cast<const f32x4*>(table + r * DIM) + i;
+        float s = 0.0f;
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            const f32x4 v = p[16 * t];
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            uint32_t b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bad |= !(fabsf(e[j]) <= 3.0e38f);  // NaN, inf, and what bf16 would round to inf
+                s = __builtin_fmaf(e[j], e[j], s);
+                const uint32_t u = __float_as_uint(e[j]);
+                b[j] = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;  // round to nearest even
+            }
+            if (live) *reinterpret_cast<uint2*>(mirror + r * DIM + 64 * t + 4 * i) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+        }
+        s = row16_sum(s);
+        const unsigned long long bm = __ballot(bad);
+        const bool any_bad = ((bm >> (lane & 48)) & 0xFFFFull) != 0ull;
+        if (live && i == 0) xx[r] = (any_bad || !(s >= 1.0e-30f && s <= 1.0e30f)) ? -1.0f : s;
+    }
+}
+
+// stage 1: every row's coarse distance key (0 for the marked rows) from the mirror; geometry of knn_scan_kernel with
+// rows of dim * 2 bytes: lane i of a 16-lane group loads the 16 bytes (8 bf16) at element 128 u + 8 i of its row
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void knn_scan_coarse_kernel(const uint16_t* __restrict__ mirror, const float* __restrict__ xx,
+                                                              uint64_t n_rows, const float* __restrict__ q,
+                                                              uint32_t* __restrict__ all_keys) {
+    static_assert(NCH % 2 == 0, "rows of whole 256-byte bf16 chunks");
+    constexpr int DIM = NCH * 64, U = NCH / 2;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const uint32_t wave = blockIdx.x * 4 + wib, n_waves = gridDim.x * 4;
+    float qf[U][8];
+    float sq;
+    {
+        float s = 0.0f;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                qf[u][e] = q[128 * u + 8 * i + e];
+                s = __builtin_fmaf(qf[u][e], qf[u][e], s);
+            }
+        sq = sqrtf(row16_sum(s));
+    }
+    const uint64_t n_tiles = (n_rows + 63) >> 6;
+    auto load_row = [&](u32x4 (&x)[U], uint64_t r) {
+        r = r < n_rows ? r : n_rows - 1;
+        const u32x4* p = reinterpret_cast<const u32x4*>(mirror + r * DIM) + i;
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p + 16 * u);
+    };
+    for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
+        float mydot = 0.0f;
+        const uint64_t row0 = (tile << 6) + 16 * g;
+        auto reduce_row = [&](const u32x4 (&x)[U], int it) {
+            float a[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t w[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[2 * j] = __builtin_fmaf(qf[u][2 * j], __uint_as_float(w[j] << 16), a[2 * j]);
+                    a[2 * j + 1] = __builtin_fmaf(qf[u][2 * j + 1], __uint_as_float(w[j] & 0xFFFF0000u), a[2 * j + 1]);
+                }
+            }
+            const float d = row16_sum(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
+            if (i == it) mydot = d;
+        };
+        u32x4 xa[U], xb[U];
+        load_row(xa, row0);
+#pragma unroll 1
+        for (int it = 0; it < 16; it += 2) {
+            load_row(xb, row0 + it + 1);
+            reduce_row(xa, it);
+            load_row(xa, row0 + (it + 2 < 16 ? it + 2 : 15));
+            reduce_row(xb, it + 1);
+        }
+        const uint64_t r = (tile << 6) + lane;
+        if (r < n_rows) {
+            const float s = xx[r];
+            all_keys[r] = s < 0.0f ? 0u : dist_to_u32(1.0f - mydot / (sq * sqrtf(s)));
+        }
+    }
+}
+
+// the candidates: rows whose coarse key is <= key(t + band), t = the k-th smallest coarse distance (from the three
+// distance passes of knn_select_hist_kernel); count may exceed cap (stage 2 then hands over to the single-pass scan)
+__global__ __launch_bounds__(256) void knn_prefilter_collect_kernel(const uint32_t* __restrict__ keys, uint64_t n_rows, uint32_t k,
+                                                                    const uint32_t* __restrict__ hist, SelState* __restrict__ states,
+                                                                    float band, uint32_t cap, uint32_t* __restrict__ cand_rows,
+                                                                    uint32_t* __restrict__ count) {
+    const SelState st = sel_advance(hist, states, 3, k, n_rows);
+    uint32_t B = 0xFFFFFFFFu;  // fewer rows than k, or a NaN at rank k: everything
+    if (n_rows >= k && st.fixed >= 1) {
+        const uint64_t T = st.prefix | ((1ull << sel_shift(st.fixed - 1)) - 1ull);  // undecided digits: all ones (an upper bound)
+        const uint32_t T32 = (uint32_t)(T >> 32);
+        const float t = u32_to_dist(T32);
+        if (T32 != 0xFFFFFFFFu && t == t) B = dist_to_u32(t + band);
+    }
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * 256) {
+        if (keys[r] <= B) {
+            const uint32_t at = atomicAdd(count, 1u);
+            if (at < cap) cand_rows[at] = (uint32_t)r;
+        }
+    }
+}
+
+// stage 2: the candidates' exact keys — RowAcc, row16_sum and the distance expression of knn_scan_kernel, one 16-lane
+// group per row.  *count > cap: nothing is computed and *fallback becomes 1.
+template <int NCH>
+__global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restrict__ table, const float* __restrict__ q,
+                                                          const uint32_t* __restrict__ cand_rows, const uint32_t* __restrict__ count,
+                                                          uint32_t cap, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ fallback) {
+    constexpr int DIM = NCH * 64;
+    const uint32_t C = *count;
+    if (C > cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *fallback = 1u;
+        return;
+    }
+    const int lane = threadIdx.x & 63, i = lane & 15;
+    f32x4 qf[NCH];
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) qf[t] = *reinterpret_cast<const f32x4*>(q + 64 * t + 4 * i);
+    float sq;
+    {
+        RowAcc<NCH> a; a.zero();
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) a.step(qf[t], qf[t]);
+        sq = sqrtf(a.sumsq());
+    }
+    const uint32_t group = (blockIdx.x * 256 + threadIdx.x) >> 4, n_groups = (gridDim.x * 256) >> 4;
+    for (uint32_t c0 = group; c0 < ((C + n_groups - 1) / n_groups) * n_groups; c0 += n_groups) {
+        const bool live = c0 < C;
+        const uint32_t row = cand_rows[live ? c0 : 0];
+        const f32x4* p = reinterpret_cast<const f32x4*>(table + (uint64_t)row * DIM) + i;
+        RowAcc<NCH> a; a.zero();
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) a.step(qf[t], p[16 * t]);
+        const float d = a.dot(), s = a.sumsq();
+        if (live && i == 0) keys_out[c0] = make_key(1.0f - d / (sq * sqrtf(s)), row);
+    }
+}
+
+// the k smallest of the (<= PREF_CAP) candidate keys, ascending, KEY_MAX behind them; nothing when *fallback is set
+__global__ __launch_bounds__(1024) void knn_topk_sort_kernel(const uint64_t* __restrict__ in, const uint32_t* __restrict__ count,
+                                                             const uint32_t* __restrict__ fallback, uint32_t k, uint64_t* __restrict__ out) {
+    __shared__ uint64_t buf[PREF_CAP];
+    if (*fallback) return;
+    const uint32_t n = min(*count, PREF_CAP);
+    int np = 64;
+    while ((uint32_t)np < n) np <<= 1;
+    for (int j = threadIdx.x; j < np; j += 1024) buf[j] = (uint32_t)j < n ? in[j] : KEY_MAX;
+    __syncthreads();
+    for (int kk = 2; kk <= np; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int p = threadIdx.x; p < np / 2; p += 1024) {
+                const int a = ((p & ~(j - 1)) << 1) | (p & (j - 1)), b = a | j;
+                const uint64_t x = buf[a], y = buf[b];
+                const bool up = (a & kk) == 0;
+                if ((x > y) == up) { buf[a] = y; buf[b] = x; }
+            }
+            __syncthreads();
+        }
+    for (uint32_t j = threadIdx.x; j < k; j += 1024) out[j] = j < (uint32_t)np ? buf[j] : KEY_MAX;
+}
+
 // Q queries in one pass over the table (throughput variant).  Same per-row
 // arithmetic per query, so results equal Q single-query scans.  q: [NQ][dim].
 template <int NCH, int NQ>
@@ -516,9 +718,11 @@ __global__ __launch_bounds__(256) void knn_scan_batched_kernel(const float* __re
 template <class Top>
 __global__ __launch_bounds__(256) void knn_merge_kernel(const uint64_t* __restrict__ in, uint32_t n_lists,
                                                         uint32_t k, uint32_t lpb, uint64_t* __restrict__ out,
-                                                        size_t in_stride, size_t out_stride) {
+                                                        size_t in_stride, size_t out_stride,
+                                                        const uint32_t* __restrict__ run_if = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint64_t wave_best[4][64];  // register form hands its lists over through here
+    if (run_if && *run_if == 0u) return;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     in += blockIdx.y * in_stride;
     out += blockIdx.y * out_stride;
@@ -638,11 +842,15 @@ __host__ __device__ inline uint64_t id_of_local(const IdMap& m, uint64_t local) 
 }
 
 // keys (ascending, KEY_MAX = none) -> (id, distance); one thread per result slot.
+// prefilter_keys / fallback (nullable): while *fallback == 0 the keys come from prefilter_keys instead
 __global__ void knn_finalize_kernel(const uint64_t* __restrict__ keys, uint32_t n, IdMap map,
                                     uint64_t* __restrict__ idx, float* __restrict__ dist,
-                                    size_t key_stride, size_t out_stride) {
+                                    size_t key_stride, size_t out_stride,
+                                    const uint64_t* __restrict__ prefilter_keys = nullptr,
+                                    const uint32_t* __restrict__ fallback = nullptr) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
+    if (fallback && *fallback == 0u) keys = prefilter_keys;
     const uint64_t key = keys ? keys[blockIdx.y * key_stride + j] : KEY_MAX;
     uint64_t* oi = idx + blockIdx.y * out_stride;
     float* od = dist + blockIdx.y * out_stride;

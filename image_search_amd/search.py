@@ -87,6 +87,16 @@ class EmbeddingTable:
     def reserve(self, rows: int):
         check(lib().mi_knn_reserve(self._h, rows))
 
+    def set_option(self, key: str, value: int):
+        """mi_knn_set_option: "prefilter" = 1 turns on the two-stage exact search (bf16 mirror, + 50 % memory)."""
+        check(lib().mi_knn_set_option(self._h, key.encode(), int(value)))
+
+    def prefilter_stats(self):
+        """(rows re-evaluated by stage 2, fell back to the single pass) of the most recent single-query search"""
+        c, f = ctypes.c_uint32(), ctypes.c_uint32()
+        check(lib().mi_knn_prefilter_stats(self._h, ctypes.byref(c), ctypes.byref(f)))
+        return c.value, bool(f.value)
+
     def insert(self, embeddings: np.ndarray):
         """db.insert("image").content(rows) (clip.rs:125-137): ids are insertion ordinals."""
         e = _f32(embeddings).reshape(-1, self.dim)

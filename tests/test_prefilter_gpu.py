@@ -1,0 +1,108 @@
+"""Two-stage exact search (mi_knn_set_option "prefilter"): ids AND distance bits must equal the single-pass scan's on
+every corpus, including the ones built to defeat the bf16 prefilter (it then hands over to the single pass on the device)."""
+import numpy as np
+import pytest
+
+from image_search_amd.search import EmbeddingTable
+
+pytestmark = pytest.mark.gpu
+DIM = 768
+N = 300_000  # above the 2^18-row threshold of the prefilter; 0.9 GB of fp32 rows
+
+
+def _both(t, q, k):
+    t.set_option("prefilter", 0)
+    a = t.knn(q, k)
+    t.set_option("prefilter", 1)
+    b = t.knn(q, k)
+    return a, b
+
+
+def _same(a, b):
+    assert np.array_equal(a[0], b[0])
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def table(built):
+    t = EmbeddingTable(DIM, 0)
+    t.reserve(N + 4096)
+    t.insert_synthetic(7, 0, N)
+    yield t
+    t.close()
+
+
+@pytest.mark.parametrize("k", [1, 10, 64])
+def test_random_corpus_matches_the_single_pass_bit_for_bit(table, k):
+    rng = np.random.default_rng(k)
+    for j in range(4):
+        q = rng.standard_normal(DIM).astype(np.float32)
+        if j == 3:
+            q = table.rows(12345, 1)[0].copy()  # a stored row as the query: distance ~0 at rank 0
+        _same(*_both(table, q, k))
+        cand, fell_back = table.prefilter_stats()
+        assert not fell_back and k <= cand <= 40 * k + 64, (cand, fell_back)  # the two stages answered, from a handful of rows
+
+
+def test_rows_appended_after_the_mirror_was_built_are_found(table):
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal(DIM).astype(np.float32)
+    table.set_option("prefilter", 1)
+    before = table.knn(q, 5)
+    n0 = len(table)
+    table.insert((q[None, :] * np.array([[1.0], [2.5], [0.5]], np.float32)).astype(np.float32))  # three rows at distance ~0
+    after = table.knn(q, 5)
+    assert set(after[0][:3].tolist()) == {n0, n0 + 1, n0 + 2} and np.array_equal(after[0][3:], before[0][:2])
+    _same(*_both(table, q, 5))
+
+
+def test_rows_the_error_bound_does_not_cover_are_always_rescored(table):
+    """non-finite, huge and vanishing rows: marked in the mirror, evaluated from the fp32 rows like everything that matters"""
+    rng = np.random.default_rng(4)
+    q = rng.standard_normal(DIM).astype(np.float32)
+    odd = rng.standard_normal((6, DIM)).astype(np.float32)
+    odd[0, 5] = np.nan
+    odd[1, 9] = np.inf
+    odd[2] *= np.float32(3.2e38) / np.abs(odd[2]).max()   # finite in fp32, inf in bf16
+    odd[3] = 0.0                                          # zero norm: NaN distance, ranked last by both paths
+    odd[4] = q * np.float32(1e-17)                        # squared norm below the stored-norm window; true distance ~0
+    odd[5] = q * np.float32(1e19)
+    table.insert(odd)
+    for k in (3, 64):
+        _same(*_both(table, q, k))
+    table.set_option("prefilter", 1)
+    assert len(table) - 2 in table.knn(q, 3)[0].tolist()  # the 1e-17-scaled copy of the query is among the nearest
+
+
+def test_a_corpus_inside_the_error_band_falls_back_to_the_single_pass(built):
+    """every row within 2 eps of the k-th: more candidates than the buffer holds -> the gated single-pass scan answers"""
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal(DIM).astype(np.float32)
+    t = EmbeddingTable(DIM, 0)
+    chunk = 50_000
+    for i in range(6):  # 300 k rows, all within 1e-4 (relative) of one direction
+        rows = base[None, :] * (1.0 + 1e-4 * rng.standard_normal((chunk, 1))).astype(np.float32)
+        rows += (1e-4 * rng.standard_normal((chunk, DIM))).astype(np.float32)
+        t.insert(rows.astype(np.float32))
+    q = (base + 0.01 * rng.standard_normal(DIM)).astype(np.float32)
+    for k in (1, 10, 64):
+        _same(*_both(t, q, k))
+        cand, fell_back = t.prefilter_stats()
+        assert fell_back and cand > 4096
+    # and exact duplicates: ties must break by id on both paths
+    t2 = EmbeddingTable(DIM, 0)
+    for i in range(6):
+        t2.insert(np.repeat(base[None, :], chunk, 0))
+    _same(*_both(t2, q, 10))
+    assert t2.knn(q, 10)[0].tolist() == list(range(10))
+    t.close()
+    t2.close()
+
+
+def test_option_errors(built):
+    t = EmbeddingTable(DIM, 0)
+    with pytest.raises(RuntimeError, match="unknown option"):
+        t.set_option("nope", 1)
+    with pytest.raises(RuntimeError, match="0 or 1"):
+        t.set_option("prefilter", 2)
+    t.close()
