@@ -104,8 +104,9 @@ struct mi_knn {
     uint64_t mirror_rows = 0;
     size_t mirror_cap = 0, xx_cap = 0;
     uint32_t* d_pref_rows = nullptr;
-    uint64_t* d_pref_keys = nullptr;   // [2 * PREF_CAP]: candidates' keys, then the k best
-    size_t pref_rows_cap = 0, pref_keys_cap = 0;
+    uint64_t* d_pref_keys = nullptr;   // [PREF_CAP + 4096]: candidates' keys, then the k best
+    uint32_t* d_pref_flag = nullptr;   // {candidate count, fallback}
+    size_t pref_rows_cap = 0, pref_keys_cap = 0, pref_flag_cap = 0;
     // Order across caller streams.  `writes`: the last append (a search must see every row counted in
     // `rows`).  `reads`: the last search (searches share the workspace above, and a reallocation of the
     // table must wait for them).  An append only ever writes rows beyond `rows`, so it does not wait

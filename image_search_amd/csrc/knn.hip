@@ -133,18 +133,20 @@ void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint
     }
 }
 
-// Two-stage exact search (knn_kernels.h "bf16 mirror as prefilter"): k <= 64, dim a multiple of 128, enough rows for the
-// saved bytes to outweigh ten short launches.  Leaves the answer's keys in d_pref_keys[PREF_CAP ..] and *fallback == 0,
-// or *fallback == 1: the caller enqueues the single-pass scan behind it, gated by that word.
+// Two-stage exact search (knn_kernels.h "bf16 mirror as prefilter"): k <= 4096 (the single pass behind it must be one of
+// the two gated forms: register lists, or the radix select), dim a multiple of 128, enough rows for the saved bytes to
+// outweigh a dozen short launches.  Leaves the answer's keys in d_pref_keys[PREF_CAP ..] and *fallback == 0, or
+// *fallback == 1: the caller enqueues the single pass behind it, gated by that word.
 constexpr uint64_t PREF_MIN_ROWS = 1u << 18;
 bool prefilter_applies(const mi_knn* t, uint32_t k) {
-    return t->prefilter && k <= 64 && t->dim % 128 == 0 && t->rows >= PREF_MIN_ROWS;
+    return t->prefilter && (k <= 64 || (k <= 4096 && t->select_path)) && t->dim % 128 == 0 && t->rows >= PREF_MIN_ROWS;
 }
 uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s) {
     ensure(t, (void**)&t->d_keys32, &t->keys32_cap, (size_t)t->cap, sizeof(uint32_t));
     ensure(t, (void**)&t->d_sel, &t->sel_cap, (size_t)6 * SEL_BINS + 64, sizeof(uint32_t));
     ensure(t, (void**)&t->d_pref_rows, &t->pref_rows_cap, (size_t)PREF_CAP, sizeof(uint32_t));
-    ensure(t, (void**)&t->d_pref_keys, &t->pref_keys_cap, (size_t)2 * PREF_CAP, sizeof(uint64_t));
+    ensure(t, (void**)&t->d_pref_keys, &t->pref_keys_cap, (size_t)PREF_CAP + 4096, sizeof(uint64_t));
+    ensure(t, (void**)&t->d_pref_flag, &t->pref_flag_cap, (size_t)4, sizeof(uint32_t));
     if (t->mirror_cap < (size_t)t->cap * t->dim || t->xx_cap < (size_t)t->cap) t->mirror_rows = 0;  // (re)allocated below: rebuild
     t->mirror_rows = std::min(t->mirror_rows, t->rows);
     ensure(t, (void**)&t->d_mirror, &t->mirror_cap, (size_t)t->cap * t->dim, sizeof(uint16_t));
@@ -152,10 +154,11 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s)
     const uint64_t n_tiles = (t->rows + 63) / 64;
     const uint32_t blocks = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 4, (n_tiles + 3) / 4));
     const uint32_t hb = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 8, (t->rows + 255) / 256);
-    uint32_t* count = t->d_sel + 6 * SEL_BINS;
+    uint32_t* count = t->d_pref_flag;  // (not in d_sel: the gated radix select behind this pass clears that)
     uint32_t* fallback = count + 1;
     SelState* states = reinterpret_cast<SelState*>(t->d_sel + 6 * SEL_BINS + 4);
     HIP_CHECK(hipMemsetAsync(t->d_sel, 0, ((size_t)6 * SEL_BINS + 64) * sizeof(uint32_t), s));
+    HIP_CHECK(hipMemsetAsync(t->d_pref_flag, 0, 4 * sizeof(uint32_t), s));
     const float eps = 0x1p-9f + 4.1f * (float)(t->dim + 8) * 0x1p-24f + 2e-6f;
     switch (t->dim / 64) {
 #define MI_CASE(NCH)                                                                                                     \
@@ -180,13 +183,16 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s)
 #undef MI_CASE
         default: fail(MI_ERR_UNSUPPORTED, "dim %u: the prefilter is built for dim/64 in {2,4,8,12,16}", t->dim);
     }
-    hipLaunchKernelGGL(knn_topk_sort_kernel, dim3(1), dim3(1024), 0, s, t->d_pref_keys, count, fallback, k, t->d_pref_keys + PREF_CAP);
+    static DevOnce once;
+    allow_lds_once(once, knn_topk_sort_kernel, (int)(PREF_CAP * sizeof(uint64_t)));
+    hipLaunchKernelGGL(knn_topk_sort_kernel, dim3(1), dim3(1024), PREF_CAP * sizeof(uint64_t), s, t->d_pref_keys, count, fallback, k,
+                       t->d_pref_keys + PREF_CAP);
     HIP_CHECK(hipGetLastError());
     return fallback;
 }
 
 // 64 < k <= 4096: every row's distance key, then the k smallest (distance, id) keys by radix select (knn_kernels.h)
-void select_pass(mi_knn* t, const float* d_q, uint32_t k, uint64_t* keys_out, hipStream_t s) {
+void select_pass(mi_knn* t, const float* d_q, uint32_t k, uint64_t* keys_out, hipStream_t s, const uint32_t* run_if = nullptr) {
     const uint64_t n_tiles = (t->rows + 63) / 64;
     uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 4, (n_tiles + 3) / 4);
     blocks = std::max(blocks, 1u);
@@ -198,7 +204,7 @@ void select_pass(mi_knn* t, const float* d_q, uint32_t k, uint64_t* keys_out, hi
 #define MI_CASE(NCH)                                                                                          \
     case NCH:                                                                                                 \
         hipLaunchKernelGGL((knn_scan_kernel<NCH, WaveTopReg, 1>), dim3(blocks), dim3(256), 0, s, t->table, t->rows, d_q, k, \
-                           (const uint64_t*)nullptr, (uint64_t*)nullptr, t->d_keys32);                        \
+                           (const uint64_t*)nullptr, (uint64_t*)nullptr, t->d_keys32, run_if);                \
         break;
         MI_CASE(1) MI_CASE(2) MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16)
 #undef MI_CASE
@@ -209,9 +215,9 @@ void select_pass(mi_knn* t, const float* d_q, uint32_t k, uint64_t* keys_out, hi
     uint32_t* count = t->d_sel + 6 * SEL_BINS;
     SelState* states = reinterpret_cast<SelState*>(t->d_sel + 6 * SEL_BINS + 4);  // 6 states of 24 bytes behind the counter
     for (int p = 0; p < 6; ++p)
-        hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, p, t->d_sel, states);
-    hipLaunchKernelGGL(knn_select_collect_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, t->d_sel, states, t->d_cand, count);
-    hipLaunchKernelGGL(knn_select_sort_kernel, dim3(1), dim3(1024), 0, s, t->d_cand, count, k, keys_out);
+        hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, p, t->d_sel, states, run_if);
+    hipLaunchKernelGGL(knn_select_collect_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, t->d_sel, states, t->d_cand, count, run_if);
+    hipLaunchKernelGGL(knn_select_sort_kernel, dim3(1), dim3(1024), 0, s, t->d_cand, count, k, keys_out, run_if);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -224,19 +230,21 @@ void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float*
     }
     const uint32_t passes = (k + 1023) / 1024;
     ensure(t, (void**)&t->d_keys, &t->keys_cap, (size_t)std::max<uint32_t>(passes * 1024, 4096), sizeof(uint64_t));
+    t->last_prefiltered = prefilter_applies(t, k);
+    if (t->last_prefiltered) {
+        const uint32_t* fallback = prefilter_pass(t, d_q, k, s);
+        // the single pass, every kernel of it returning at once unless *fallback
+        if (k <= 64) one_pass<WaveTopReg>(t, d_q, k, nullptr, t->d_keys, s, fallback);
+        else select_pass(t, d_q, k, t->d_keys, s, fallback);
+        hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, id_map(t),
+                           d_idx, d_dist, (size_t)0, (size_t)0, t->d_pref_keys + PREF_CAP, fallback);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (k > 64 && k <= 4096 && t->select_path) {
         select_pass(t, d_q, k, t->d_keys, s);
         hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, id_map(t),
                            d_idx, d_dist, (size_t)0, (size_t)0);
-        HIP_CHECK(hipGetLastError());
-        return;
-    }
-    t->last_prefiltered = prefilter_applies(t, k);
-    if (t->last_prefiltered) {
-        const uint32_t* fallback = prefilter_pass(t, d_q, k, s);
-        one_pass<WaveTopReg>(t, d_q, k, nullptr, t->d_keys, s, fallback);  // returns at once unless *fallback
-        hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, id_map(t),
-                           d_idx, d_dist, (size_t)0, (size_t)0, t->d_pref_keys + PREF_CAP, fallback);
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -335,7 +343,7 @@ void mi_knn_free(mi_knn* t) {
     if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
     for (void* p : {(void*)t->table, (void*)t->d_q, (void*)t->d_cand, (void*)t->d_tmp, (void*)t->d_keys,
                     (void*)t->d_idx, (void*)t->d_dist, (void*)t->d_keys32, (void*)t->d_sel, (void*)t->d_mirror,
-                    (void*)t->d_xx, (void*)t->d_pref_rows, (void*)t->d_pref_keys})
+                    (void*)t->d_xx, (void*)t->d_pref_rows, (void*)t->d_pref_keys, (void*)t->d_pref_flag})
         if (p) (void)hipFree(p);
     delete t;
 }
@@ -372,7 +380,7 @@ int mi_knn_prefilter_stats(mi_knn* t, uint32_t* candidates, uint32_t* fell_back)
         DeviceGuard g(t->device);
         t->reads.sync();
         uint32_t w[2] = {0, 0};
-        HIP_CHECK(hipMemcpy(w, t->d_sel + 6 * SEL_BINS, sizeof w, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(w, t->d_pref_flag, sizeof w, hipMemcpyDeviceToHost));
         *candidates = w[0]; *fell_back = w[1];
     });
 }

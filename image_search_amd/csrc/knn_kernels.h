@@ -351,8 +351,10 @@ __device__ inline SelState sel_advance(const uint32_t* __restrict__ hist, SelSta
 
 // pass `p`: histogram of digit p over the keys that match the prefix chosen so far
 __global__ __launch_bounds__(256) void knn_select_hist_kernel(const uint32_t* __restrict__ keys, uint64_t n_rows, uint32_t k,
-                                                              int p, uint32_t* __restrict__ hist, SelState* __restrict__ states) {
+                                                              int p, uint32_t* __restrict__ hist, SelState* __restrict__ states,
+                                                              const uint32_t* __restrict__ run_if = nullptr) {
     __shared__ uint32_t lh[SEL_BINS];
+    if (run_if && *run_if == 0u) return;
     const SelState st = sel_advance(hist, states, p, k, n_rows);
     if (st.done) return;
     for (int j = threadIdx.x; j < SEL_BINS; j += 256) lh[j] = 0;
@@ -399,7 +401,9 @@ __global__ __launch_bounds__(256) void knn_select_hist_kernel(const uint32_t* __
 // every key <= the k-th smallest goes to out (unordered); count = how many (== min(k, n_rows))
 __global__ __launch_bounds__(256) void knn_select_collect_kernel(const uint32_t* __restrict__ keys, uint64_t n_rows, uint32_t k,
                                                                  const uint32_t* __restrict__ hist, SelState* __restrict__ states,
-                                                                 uint64_t* __restrict__ out, uint32_t* __restrict__ count) {
+                                                                 uint64_t* __restrict__ out, uint32_t* __restrict__ count,
+                                                                 const uint32_t* __restrict__ run_if = nullptr) {
+    if (run_if && *run_if == 0u) return;
     const SelState st = sel_advance(hist, states, 6, k, n_rows);
     // the k-th key: the chosen digits; when a whole group was taken its lower digits are free (all ones);
     // fewer rows than k: every key
@@ -416,8 +420,10 @@ __global__ __launch_bounds__(256) void knn_select_collect_kernel(const uint32_t*
 
 // one block: the (<= 4096) collected keys ascending into out[0, k), KEY_MAX behind them
 __global__ __launch_bounds__(1024) void knn_select_sort_kernel(const uint64_t* __restrict__ in, const uint32_t* __restrict__ count,
-                                                               uint32_t k, uint64_t* __restrict__ out) {
+                                                               uint32_t k, uint64_t* __restrict__ out,
+                                                               const uint32_t* __restrict__ run_if = nullptr) {
     __shared__ uint64_t buf[4096];
+    if (run_if && *run_if == 0u) return;
     const uint32_t n = min(*count, k);
     int np = 64;
     while ((uint32_t)np < k) np <<= 1;  // the power of two that holds k (<= 4096)
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(1024) void knn_select_sort_kernel(const uint64_t* _
     for (uint32_t j = threadIdx.x; j < k; j += 1024) out[j] = buf[j];
 }
 
-// ---- two-stage EXACT search: a bf16 mirror as prefilter (opt-in, k <= 64) ----------------------------------------
+// ---- two-stage EXACT search: a bf16 mirror as prefilter (opt-in, k <= 4096) --------------------------------------
 // The scan above is bound by the bytes of the table; 288 GB of HBM per GPU leave room to keep the rows a second time
 // at half the width.  Stage 1 scans the bf16 mirror (dim*2 bytes per row + a stored f32 norm) and writes every row's
 // COARSE distance key; the k-th smallest coarse distance t is found by the radix select's three distance passes;
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(1024) void knn_select_sort_kernel(const uint64_t* _
 // squared norm outside [1e-30, 1e30]) are marked in the mirror and are always candidates.  More candidates than the
 // buffer holds (adversarial corpora: everything within 2 eps of the k-th) => the single-pass scan runs instead; it is
 // enqueued behind stage 2 either way and returns at once when it is not needed (no host round trip).
-constexpr uint32_t PREF_CAP = 4096;  // candidates stage 2 accepts (one block sorts their keys)
+constexpr uint32_t PREF_CAP = 16384;  // candidates stage 2 accepts (one block sorts their keys in 128 KiB of LDS)
 
 // rows [first, end) of the table -> bf16 mirror rows + stored squared norms (-1 = "always a candidate")
 template <int NCH>
@@ -612,10 +618,12 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     }
 }
 
-// the k smallest of the (<= PREF_CAP) candidate keys, ascending, KEY_MAX behind them; nothing when *fallback is set
+// the k smallest of the (<= PREF_CAP) candidate keys, ascending, KEY_MAX behind them; nothing when *fallback is set.
+// One block, PREF_CAP * 8 bytes of dynamic LDS; the sort runs over the power of two that holds the candidates.
 __global__ __launch_bounds__(1024) void knn_topk_sort_kernel(const uint64_t* __restrict__ in, const uint32_t* __restrict__ count,
                                                              const uint32_t* __restrict__ fallback, uint32_t k, uint64_t* __restrict__ out) {
-    __shared__ uint64_t buf[PREF_CAP];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
     if (*fallback) return;
     const uint32_t n = min(*count, PREF_CAP);
     int np = 64;

@@ -168,15 +168,15 @@ int mi_clip_embed_text(mi_clip* m, const int32_t* input_ids, size_t n, float* ou
 int mi_knn_create(uint32_t dim, int device, mi_knn** out);
 void mi_knn_free(mi_knn* t);
 int mi_knn_set_base(mi_knn* t, uint64_t base);
-/* Options of a shard.  "prefilter" = 1: two-stage EXACT search for k <= 64 on shards of >= 2^18 rows — a bf16 mirror of the
+/* Options of a shard.  "prefilter" = 1: two-stage EXACT search for k <= 4096 on shards of >= 2^18 rows — a bf16 mirror of the
  * rows (+ 50 % device memory; built by the next search, kept up to date by every later one) is scanned first, the rows
  * within a data-independent error bound of the k-th coarse distance are re-evaluated from the fp32 rows with the
- * single-pass arithmetic: same ids, same distance bits, about half the bytes per query.  Corpora that put more than 4096
+ * single-pass arithmetic: same ids, same distance bits, about half the bytes per query.  Corpora that put more than 16384
  * rows inside the bound fall back to the single pass on the device.  0 (default) frees the mirror. */
 int mi_knn_set_option(mi_knn* t, const char* key, int value);
 /* Of the most recent single-query search of this shard (waits for it): how many rows stage 2 re-evaluated, and whether the
  * single pass had to answer instead (then `candidates` is the count that did not fit).  Both 0 when the search did not
- * go through the prefilter (option off, k > 64, fewer than 2^18 rows, batched searches). */
+ * go through the prefilter (option off, k > 4096, fewer than 2^18 rows, batched searches). */
 int mi_knn_prefilter_stats(mi_knn* t, uint32_t* candidates, uint32_t* fell_back);
 int mi_knn_reserve(mi_knn* t, uint64_t rows); /* capacity hint; keeps contents */
 int mi_knn_size(const mi_knn* t, uint64_t* rows);

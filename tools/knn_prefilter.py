@@ -15,7 +15,7 @@ dq = torch.from_numpy(synth.corpus_rows(1, 0, 16)).cuda()
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
 s = torch.cuda.current_stream().cuda_stream
 out = {"rows": NP, "dim": 768, "results": []}
-for k in (1, 10, 64):
+for k in (1, 10, 64, 1000):
     res = {}
     for mode in (0, 1):
         t.set_option("prefilter", mode)
