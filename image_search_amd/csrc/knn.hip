@@ -159,7 +159,7 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s)
     SelState* states = reinterpret_cast<SelState*>(t->d_sel + 6 * SEL_BINS + 4);
     HIP_CHECK(hipMemsetAsync(t->d_sel, 0, ((size_t)6 * SEL_BINS + 64) * sizeof(uint32_t), s));
     HIP_CHECK(hipMemsetAsync(t->d_pref_flag, 0, 4 * sizeof(uint32_t), s));
-    const float eps = 0x1p-9f + 4.1f * (float)(t->dim + 8) * 0x1p-24f + 2e-6f;
+    const float eps = 0x1p-8f + 4.1f * (float)(t->dim + 8) * 0x1p-24f + 2e-6f;  // bf16: 8 significant bits, unit roundoff 2^-8
     switch (t->dim / 64) {
 #define MI_CASE(NCH)                                                                                                     \
     case NCH:                                                                                                            \

@@ -451,14 +451,16 @@ __global__ __launch_bounds__(1024) void knn_select_sort_kernel(const uint64_t* _
 //
 // Why it is exact.  With eps >= |coarse - exact| for every row: the k rows of smallest coarse distance have exact
 // distances <= t + eps, so the exact k-th distance is <= t + eps, so every row of the exact answer has coarse distance
-// <= t + 2 eps and is a candidate.  The bound: x~ = bf16(x) rounds to nearest, |x~_j - x_j| <= 2^-9 |x_j|, hence
-// |q.x~ - q.x| <= 2^-9 sum|q_j x_j| <= 2^-9 |q| |x| (Cauchy-Schwarz), i.e. 2^-9 on the cosine; the fp32 summations of
-// both sides (any order) add <= 2 gamma_n each with gamma_n = (n + 8) 2^-24, the norms (stored vs recomputed) another
-// 2 gamma_n, the divisions / square roots / subtraction a few ulp of O(1):  eps = 2^-9 + 4.1 (dim + 8) 2^-24 + 2e-6
-// (2.14e-3 at dim 768), independent of the data.  Rows the bound does not cover (a non-finite or > 3e38 element, a
+// <= t + 2 eps and is a candidate.  The bound: x~ = bf16(x) rounds to nearest (8 significant bits: unit roundoff 2^-8),
+// |x~_j - x_j| <= 2^-8 |x_j|, hence |q.x~ - q.x| <= 2^-8 sum|q_j x_j| <= 2^-8 |q| |x| (Cauchy-Schwarz), i.e. 2^-8 on the
+// cosine; the fp32 summations of both sides (any order) add <= 2 gamma_n each with gamma_n = (n + 8) 2^-24, the norms
+// (stored vs recomputed) another 2 gamma_n, the divisions / square roots / subtraction a few ulp of O(1):
+// eps = 2^-8 + 4.1 (dim + 8) 2^-24 + 2e-6 (4.10e-3 at dim 768), independent of the data; tests/test_prefilter_bound.py
+// drives rows built to sit at the rounding's worst case against it.  Rows the bound does not cover (a non-finite or > 3e38 element, a
 // squared norm outside [1e-30, 1e30]) are marked in the mirror and are always candidates.  More candidates than the
 // buffer holds (adversarial corpora: everything within 2 eps of the k-th) => the single-pass scan runs instead; it is
 // enqueued behind stage 2 either way and returns at once when it is not needed (no host round trip).
+constexpr uint32_t PREF_MARK = 0xFFFFFFFEu;  // coarse key of a marked row: no distance maps to it (NaN is 0xFFFFFFFF), it ranks behind every real one
 constexpr uint32_t PREF_CAP = 16384;  // candidates stage 2 accepts (one block sorts their keys in 128 KiB of LDS)
 
 // rows [first, end) of the table -> bf16 mirror rows + stored squared norms (-1 = "always a candidate")
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(256) void knn_mirror_kernel(const float* __restrict
     }
 }
 
-// stage 1: every row's coarse distance key (0 for the marked rows) from the mirror; geometry of knn_scan_kernel with
+// stage 1: every row's coarse distance key (PREF_MARK for the marked rows: they must not count towards the k-th) from the mirror; geometry of knn_scan_kernel with
 // rows of dim * 2 bytes: lane i of a 16-lane group loads the 16 bytes (8 bf16) at element 128 u + 8 i of its row
 template <int NCH>
 __global__ __launch_bounds__(256, 2) void knn_scan_coarse_kernel(const uint16_t* __restrict__ mirror, const float* __restrict__ xx,
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse_kernel(const uint16_t*
         const uint64_t r = (tile << 6) + lane;
         if (r < n_rows) {
             const float s = xx[r];
-            all_keys[r] = s < 0.0f ? 0u : dist_to_u32(1.0f - mydot / (sq * sqrtf(s)));
+            all_keys[r] = s < 0.0f ? PREF_MARK : dist_to_u32(1.0f - mydot / (sq * sqrtf(s)));
         }
     }
 }
@@ -572,10 +574,11 @@ __global__ __launch_bounds__(256) void knn_prefilter_collect_kernel(const uint32
         const uint64_t T = st.prefix | ((1ull << sel_shift(st.fixed - 1)) - 1ull);  // undecided digits: all ones (an upper bound)
         const uint32_t T32 = (uint32_t)(T >> 32);
         const float t = u32_to_dist(T32);
-        if (T32 != 0xFFFFFFFFu && t == t) B = dist_to_u32(t + band);
+        if (T32 < PREF_MARK && t == t) B = dist_to_u32(t + band);  // (fewer than k unmarked rows with a real distance: everything)
     }
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * 256) {
-        if (keys[r] <= B) {
+        const uint32_t key = keys[r];
+        if (key <= B || key == PREF_MARK) {
             const uint32_t at = atomicAdd(count, 1u);
             if (at < cap) cand_rows[at] = (uint32_t)r;
         }

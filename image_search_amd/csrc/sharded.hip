@@ -214,6 +214,17 @@ int mi_knn_sharded_info(const mi_knn_sharded* t, uint64_t* rows, uint32_t* n_sha
     });
 }
 
+int mi_knn_sharded_set_option(mi_knn_sharded* t, const char* key, int value) {
+    return guarded([&] {
+        if (!t || !key) fail(MI_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> l(t->mu);
+        for (mi_knn* s : t->shard) {  // the options of mi_knn_set_option, applied to every shard
+            const int e = mi_knn_set_option(s, key, value);
+            if (e != MI_OK) fail(e, "%s", mi_last_error());
+        }
+    });
+}
+
 int mi_knn_sharded_reserve(mi_knn_sharded* t, uint64_t rows) {
     return guarded([&] {
         if (!t) fail(MI_ERR_INVALID, "null table handle");

@@ -245,6 +245,9 @@ class ShardedTable:
     def __len__(self) -> int:
         return self.info()["rows"]
 
+    def set_option(self, key: str, value: int):
+        check(lib().mi_knn_sharded_set_option(self._h, key.encode(), int(value)))
+
     def reserve(self, rows: int):
         check(lib().mi_knn_sharded_reserve(self._h, rows))
 

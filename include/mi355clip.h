@@ -236,6 +236,7 @@ int mi_knn_sharded_create(uint32_t dim, const int* devices, int n_dev, uint32_t 
 void mi_knn_sharded_free(mi_knn_sharded* t);
 /* any of the outputs may be NULL; transport: 0 = single shard, 1 = host gather, 2 = RCCL all-gather */
 int mi_knn_sharded_info(const mi_knn_sharded* t, uint64_t* rows, uint32_t* n_shards, uint32_t* block_rows, int* transport);
+int mi_knn_sharded_set_option(mi_knn_sharded* t, const char* key, int value); /* mi_knn_set_option on every shard */
 int mi_knn_sharded_reserve(mi_knn_sharded* t, uint64_t rows);
 int mi_knn_sharded_append(mi_knn_sharded* t, const float* rows, uint64_t n, uint64_t* first_id /* may be NULL */);
 int mi_knn_sharded_append_synthetic(mi_knn_sharded* t, uint64_t seed, uint64_t first_row, uint64_t n);

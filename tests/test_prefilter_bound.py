@@ -1,0 +1,55 @@
+"""The error bound behind the two-stage exact search (knn_kernels.h, "bf16 mirror as prefilter"), checked on the CPU:
+|coarse - exact| <= eps = 2^-8 + 4.1 (dim + 8) 2^-24 + 2e-6 for the cosine distance computed from bf16-rounded rows,
+on random rows and on rows built to sit at the worst case of the rounding (every element half an ulp off, signs aligned
+with the query)."""
+import numpy as np
+
+DIM = 768
+EPS = 2.0 ** -8 + 4.1 * (DIM + 8) * 2.0 ** -24 + 2e-6   # bf16 keeps 8 significant bits: unit roundoff 2^-8
+
+
+def bf16_rne(x: np.ndarray) -> np.ndarray:
+    u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def cos_dist32(q, x, xx=None):
+    """fp32 arithmetic throughout (summation order differs from the kernels': that is inside the bound's gamma terms)"""
+    q = q.astype(np.float32); x = x.astype(np.float32)
+    dot = np.float32(0)
+    for c in range(0, DIM, 64):  # chunked like the kernels, any order
+        dot = np.float32(dot + np.dot(q[c:c + 64], x[c:c + 64]).astype(np.float32))
+    qq = np.float32(np.dot(q, q)); xn = np.float32(np.dot(x, x)) if xx is None else np.float32(xx)
+    return np.float32(1) - dot / (np.sqrt(qq) * np.sqrt(xn))
+
+
+def test_bound_holds_on_random_and_on_worst_case_rows():
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for trial in range(300):
+        q = rng.standard_normal(DIM).astype(np.float32)
+        if trial % 3 == 0:
+            x = rng.standard_normal(DIM).astype(np.float32) * np.float32(10.0 ** rng.integers(-6, 7))
+        elif trial % 3 == 1:
+            x = (q + 0.05 * rng.standard_normal(DIM)).astype(np.float32)  # a near neighbour: where the ranking is decided
+        else:
+            # worst case of round-to-nearest: mantissa bits below bf16 = 0x7FFF / 0x8001 (just under / over half an ulp),
+            # the direction of each element's error chosen to push the dot product one way
+            base = (np.abs(q) * (1.0 + rng.random(DIM))).astype(np.float32)
+            u = base.view(np.uint32) & np.uint32(0xFFFF0000)
+            x = ((u | np.uint32(0x7FFF)).view(np.float32) * np.sign(q)).astype(np.float32)
+        exact = float(cos_dist32(q, x))
+        coarse = float(cos_dist32(q, bf16_rne(x), xx=np.dot(x.astype(np.float64), x.astype(np.float64))))
+        err = abs(coarse - exact)
+        worst = max(worst, err)
+        assert err <= EPS, (trial, err, EPS)
+    assert worst > 0.5 * 2.0 ** -8  # the constructed rows do come close to the bound: it is not vacuous
+    assert worst > 2.0 ** -9        # ... and a bound of 2^-9 (bf16 mistaken for 9 significant bits) would be violated
+
+
+def test_bf16_rounding_is_nearest_even():
+    x = np.array([1.0, 1.0 + 2.0 ** -8, 1.0 + 2.0 ** -7 + 2.0 ** -8, -3.14159, 1e-30, 65504.0], np.float32)
+    r = bf16_rne(x)
+    assert np.all(np.abs(r - x) <= np.abs(x) * 2.0 ** -8)
+    assert r[1] == np.float32(1.0) and r[2] == np.float32(1.0 + 2.0 ** -6)  # ties go to the even mantissa
