@@ -103,9 +103,9 @@ struct mi_knn {
     float* d_xx = nullptr;
     uint64_t mirror_rows = 0;
     size_t mirror_cap = 0, xx_cap = 0;
-    uint32_t* d_pref_rows = nullptr;
-    uint64_t* d_pref_keys = nullptr;   // [PREF_CAP + 4096]: candidates' keys, then the k best
-    uint32_t* d_pref_flag = nullptr;   // {candidate count, fallback}
+    uint32_t* d_pref_rows = nullptr;   // [2 * PREF_CAP]: candidate rows, then their exact distance keys
+    uint64_t* d_pref_keys = nullptr;   // [4096]: the k best keys of stage 2
+    uint32_t* d_pref_flag = nullptr;   // {candidate count, fallback, go}
     size_t pref_rows_cap = 0, pref_keys_cap = 0, pref_flag_cap = 0;
     // Order across caller streams.  `writes`: the last append (a search must see every row counted in
     // `rows`).  `reads`: the last search (searches share the workspace above, and a reallocation of the

@@ -135,7 +135,7 @@ void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint
 
 // Two-stage exact search (knn_kernels.h "bf16 mirror as prefilter"): k <= 4096 (the single pass behind it must be one of
 // the two gated forms: register lists, or the radix select), dim a multiple of 128, enough rows for the saved bytes to
-// outweigh a dozen short launches.  Leaves the answer's keys in d_pref_keys[PREF_CAP ..] and *fallback == 0, or
+// outweigh a dozen short launches.  Leaves the answer's keys in d_pref_keys and *fallback == 0, or
 // *fallback == 1: the caller enqueues the single pass behind it, gated by that word.
 constexpr uint64_t PREF_MIN_ROWS = 1u << 18;
 bool prefilter_applies(const mi_knn* t, uint32_t k) {
@@ -144,8 +144,9 @@ bool prefilter_applies(const mi_knn* t, uint32_t k) {
 uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s) {
     ensure(t, (void**)&t->d_keys32, &t->keys32_cap, (size_t)t->cap, sizeof(uint32_t));
     ensure(t, (void**)&t->d_sel, &t->sel_cap, (size_t)6 * SEL_BINS + 64, sizeof(uint32_t));
-    ensure(t, (void**)&t->d_pref_rows, &t->pref_rows_cap, (size_t)PREF_CAP, sizeof(uint32_t));
-    ensure(t, (void**)&t->d_pref_keys, &t->pref_keys_cap, (size_t)PREF_CAP + 4096, sizeof(uint64_t));
+    ensure(t, (void**)&t->d_cand, &t->cand_keys, (size_t)4096, sizeof(uint64_t));
+    ensure(t, (void**)&t->d_pref_rows, &t->pref_rows_cap, (size_t)2 * PREF_CAP, sizeof(uint32_t));  // rows, then their exact keys
+    ensure(t, (void**)&t->d_pref_keys, &t->pref_keys_cap, (size_t)4096, sizeof(uint64_t));
     ensure(t, (void**)&t->d_pref_flag, &t->pref_flag_cap, (size_t)4, sizeof(uint32_t));
     if (t->mirror_cap < (size_t)t->cap * t->dim || t->xx_cap < (size_t)t->cap) t->mirror_rows = 0;  // (re)allocated below: rebuild
     t->mirror_rows = std::min(t->mirror_rows, t->rows);
@@ -154,11 +155,13 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s)
     const uint64_t n_tiles = (t->rows + 63) / 64;
     const uint32_t blocks = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 4, (n_tiles + 3) / 4));
     const uint32_t hb = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 8, (t->rows + 255) / 256);
-    uint32_t* count = t->d_pref_flag;  // (not in d_sel: the gated radix select behind this pass clears that)
-    uint32_t* fallback = count + 1;
+    uint32_t* flags = t->d_pref_flag;  // {candidate count, fallback, go}; not in d_sel: the selects below clear that
+    uint32_t* key32 = t->d_pref_rows + PREF_CAP;
+    uint32_t* count2 = t->d_sel + 6 * SEL_BINS;
     SelState* states = reinterpret_cast<SelState*>(t->d_sel + 6 * SEL_BINS + 4);
-    HIP_CHECK(hipMemsetAsync(t->d_sel, 0, ((size_t)6 * SEL_BINS + 64) * sizeof(uint32_t), s));
-    HIP_CHECK(hipMemsetAsync(t->d_pref_flag, 0, 4 * sizeof(uint32_t), s));
+    const size_t sel_bytes = ((size_t)6 * SEL_BINS + 64) * sizeof(uint32_t);
+    HIP_CHECK(hipMemsetAsync(t->d_sel, 0, sel_bytes, s));
+    HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), s));
     const float eps = 0x1p-8f + 4.1f * (float)(t->dim + 8) * 0x1p-24f + 2e-6f;  // bf16: 8 significant bits, unit roundoff 2^-8
     switch (t->dim / 64) {
 #define MI_CASE(NCH)                                                                                                     \
@@ -175,20 +178,26 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s)
         for (int p = 0; p < 3; ++p)                                                                                      \
             hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, p, t->d_sel, states); \
         hipLaunchKernelGGL(knn_prefilter_collect_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, t->d_sel,   \
-                           states, 2.0f * eps, PREF_CAP, t->d_pref_rows, count);                                         \
-        hipLaunchKernelGGL((knn_rescore_kernel<NCH>), dim3(PREF_CAP / 16), dim3(256), 0, s, t->table, d_q, t->d_pref_rows, \
-                           count, PREF_CAP, t->d_pref_keys, fallback);                                                   \
+                           states, 2.0f * eps, PREF_CAP, t->d_pref_rows, flags);                                         \
+        hipLaunchKernelGGL((knn_rescore_kernel<NCH>), dim3(t->n_cu * 8), dim3(256), 0, s, t->table, d_q, t->d_pref_rows, \
+                           flags, PREF_CAP, key32);                                                                      \
         break;
         MI_CASE(2) MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16)
 #undef MI_CASE
         default: fail(MI_ERR_UNSUPPORTED, "dim %u: the prefilter is built for dim/64 in {2,4,8,12,16}", t->dim);
     }
-    static DevOnce once;
-    allow_lds_once(once, knn_topk_sort_kernel, (int)(PREF_CAP * sizeof(uint64_t)));
-    hipLaunchKernelGGL(knn_topk_sort_kernel, dim3(1), dim3(1024), PREF_CAP * sizeof(uint64_t), s, t->d_pref_keys, count, fallback, k,
-                       t->d_pref_keys + PREF_CAP);
+    // the k smallest (exact key, row) pairs of the candidates: the radix select over the two arrays, unless there were too many
+    HIP_CHECK(hipMemsetAsync(t->d_sel, 0, sel_bytes, s));
+    const uint32_t* go = flags + 2;
+    const uint32_t cb = (uint32_t)t->n_cu * 2;
+    for (int p = 0; p < 6; ++p)
+        hipLaunchKernelGGL(knn_select_hist_kernel, dim3(cb), dim3(256), 0, s, key32, (uint64_t)PREF_CAP, k, p, t->d_sel, states, go, flags,
+                           t->d_pref_rows);
+    hipLaunchKernelGGL(knn_select_collect_kernel, dim3(cb), dim3(256), 0, s, key32, (uint64_t)PREF_CAP, k, t->d_sel, states, t->d_cand, count2,
+                       go, flags, t->d_pref_rows);
+    hipLaunchKernelGGL(knn_select_sort_kernel, dim3(1), dim3(1024), 0, s, t->d_cand, count2, k, t->d_pref_keys, go);
     HIP_CHECK(hipGetLastError());
-    return fallback;
+    return flags + 1;
 }
 
 // 64 < k <= 4096: every row's distance key, then the k smallest (distance, id) keys by radix select (knn_kernels.h)
@@ -237,7 +246,7 @@ void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float*
         if (k <= 64) one_pass<WaveTopReg>(t, d_q, k, nullptr, t->d_keys, s, fallback);
         else select_pass(t, d_q, k, t->d_keys, s, fallback);
         hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, id_map(t),
-                           d_idx, d_dist, (size_t)0, (size_t)0, t->d_pref_keys + PREF_CAP, fallback);
+                           d_idx, d_dist, (size_t)0, (size_t)0, t->d_pref_keys, fallback);
         HIP_CHECK(hipGetLastError());
         return;
     }

@@ -349,12 +349,17 @@ __device__ inline SelState sel_advance(const uint32_t* __restrict__ hist, SelSta
     return st;
 }
 
-// pass `p`: histogram of digit p over the keys that match the prefix chosen so far
+// pass `p`: histogram of digit p over the keys that match the prefix chosen so far.
+// n_dev (nullable): the number of entries lives on the device (min with n_rows); row_of (nullable): the low word of
+// entry r's 64-bit key is row_of[r] instead of r (the candidates of the two-stage search: ties still break by row id).
 __global__ __launch_bounds__(256) void knn_select_hist_kernel(const uint32_t* __restrict__ keys, uint64_t n_rows, uint32_t k,
                                                               int p, uint32_t* __restrict__ hist, SelState* __restrict__ states,
-                                                              const uint32_t* __restrict__ run_if = nullptr) {
+                                                              const uint32_t* __restrict__ run_if = nullptr,
+                                                              const uint32_t* __restrict__ n_dev = nullptr,
+                                                              const uint32_t* __restrict__ row_of = nullptr) {
     __shared__ uint32_t lh[SEL_BINS];
     if (run_if && *run_if == 0u) return;
+    if (n_dev) n_rows = min(n_rows, (uint64_t)*n_dev);
     const SelState st = sel_advance(hist, states, p, k, n_rows);
     if (st.done) return;
     for (int j = threadIdx.x; j < SEL_BINS; j += 256) lh[j] = 0;
@@ -376,22 +381,26 @@ __global__ __launch_bounds__(256) void knn_select_hist_kernel(const uint32_t* __
             atomicAdd(&lh[bin], 1u);
         }
     };
-    // 4 consecutive rows per thread (one 16-byte load); the table's row count is a multiple of nothing: tail by hand
+    // 4 consecutive entries per thread (one 16-byte load); the count is a multiple of nothing: tail by hand
     const uint64_t n4 = n_rows >> 2;
     for (uint64_t q4 = (uint64_t)blockIdx.x * 256 + threadIdx.x; q4 < ((n4 + 63) & ~63ull); q4 += (uint64_t)gridDim.x * 256) {
         const bool live = q4 < n4;
         uint4 v = {0u, 0u, 0u, 0u};
-        if (live) v = reinterpret_cast<const uint4*>(keys)[q4];
         const uint64_t r0 = q4 << 2;
-        count_key(((uint64_t)v.x << 32) | (uint32_t)(r0 + 0), live);
-        count_key(((uint64_t)v.y << 32) | (uint32_t)(r0 + 1), live);
-        count_key(((uint64_t)v.z << 32) | (uint32_t)(r0 + 2), live);
-        count_key(((uint64_t)v.w << 32) | (uint32_t)(r0 + 3), live);
+        uint4 lo = {(uint32_t)r0, (uint32_t)(r0 + 1), (uint32_t)(r0 + 2), (uint32_t)(r0 + 3)};
+        if (live) {
+            v = reinterpret_cast<const uint4*>(keys)[q4];
+            if (row_of) lo = reinterpret_cast<const uint4*>(row_of)[q4];
+        }
+        count_key(((uint64_t)v.x << 32) | lo.x, live);
+        count_key(((uint64_t)v.y << 32) | lo.y, live);
+        count_key(((uint64_t)v.z << 32) | lo.z, live);
+        count_key(((uint64_t)v.w << 32) | lo.w, live);
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64) {  // the last n_rows % 4 rows
+    if (blockIdx.x == 0 && threadIdx.x < 64) {  // the last n_rows % 4 entries
         const uint64_t r = (n4 << 2) + threadIdx.x;
         const bool live = threadIdx.x < (n_rows & 3);
-        count_key(live ? (((uint64_t)keys[r] << 32) | (uint32_t)r) : 0ull, live);
+        count_key(live ? (((uint64_t)keys[r] << 32) | (row_of ? row_of[r] : (uint32_t)r)) : 0ull, live);
     }
     __syncthreads();
     for (int j = threadIdx.x; j < SEL_BINS; j += 256)
@@ -402,15 +411,18 @@ __global__ __launch_bounds__(256) void knn_select_hist_kernel(const uint32_t* __
 __global__ __launch_bounds__(256) void knn_select_collect_kernel(const uint32_t* __restrict__ keys, uint64_t n_rows, uint32_t k,
                                                                  const uint32_t* __restrict__ hist, SelState* __restrict__ states,
                                                                  uint64_t* __restrict__ out, uint32_t* __restrict__ count,
-                                                                 const uint32_t* __restrict__ run_if = nullptr) {
+                                                                 const uint32_t* __restrict__ run_if = nullptr,
+                                                                 const uint32_t* __restrict__ n_dev = nullptr,
+                                                                 const uint32_t* __restrict__ row_of = nullptr) {
     if (run_if && *run_if == 0u) return;
+    if (n_dev) n_rows = min(n_rows, (uint64_t)*n_dev);
     const SelState st = sel_advance(hist, states, 6, k, n_rows);
     // the k-th key: the chosen digits; when a whole group was taken its lower digits are free (all ones);
     // fewer rows than k: every key
     uint64_t T = KEY_MAX;
     if (n_rows >= k) T = st.fixed == 6 ? st.prefix : (st.prefix | ((1ull << sel_shift(st.fixed - 1)) - 1ull));
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * 256) {
-        const uint64_t key = ((uint64_t)keys[r] << 32) | (uint32_t)r;
+        const uint64_t key = ((uint64_t)keys[r] << 32) | (row_of ? row_of[r] : (uint32_t)r);
         if (key <= T) {
             const uint32_t at = atomicAdd(count, 1u);
             if (at < k) out[at] = key;
@@ -458,10 +470,10 @@ __global__ __launch_bounds__(1024) void knn_select_sort_kernel(const uint64_t* _
 // eps = 2^-8 + 4.1 (dim + 8) 2^-24 + 2e-6 (4.10e-3 at dim 768), independent of the data; tests/test_prefilter_bound.py
 // drives rows built to sit at the rounding's worst case against it.  Rows the bound does not cover (a non-finite or > 3e38 element, a
 // squared norm outside [1e-30, 1e30]) are marked in the mirror and are always candidates.  More candidates than the
-// buffer holds (adversarial corpora: everything within 2 eps of the k-th) => the single-pass scan runs instead; it is
-// enqueued behind stage 2 either way and returns at once when it is not needed (no host round trip).
+// buffer holds (2 M: a corpus with a fifth of its rows within 2 eps of the k-th) => the single-pass scan runs instead;
+// it is enqueued behind stage 2 either way and returns at once when it is not needed (no host round trip).
 constexpr uint32_t PREF_MARK = 0xFFFFFFFEu;  // coarse key of a marked row: no distance maps to it (NaN is 0xFFFFFFFF), it ranks behind every real one
-constexpr uint32_t PREF_CAP = 16384;  // candidates stage 2 accepts (one block sorts their keys in 128 KiB of LDS)
+constexpr uint32_t PREF_CAP = 1u << 21;  // candidates stage 2 accepts (2 M rows = 6.4 GB of fp32 rows at dim 768: a fifth of a 10 M-row pass)
 
 // rows [first, end) of the table -> bf16 mirror rows + stored squared norms (-1 = "always a candidate")
 template <int NCH>
@@ -576,27 +588,39 @@ __global__ __launch_bounds__(256) void knn_prefilter_collect_kernel(const uint32
         const float t = u32_to_dist(T32);
         if (T32 < PREF_MARK && t == t) B = dist_to_u32(t + band);  // (fewer than k unmarked rows with a real distance: everything)
     }
-    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * 256) {
-        const uint32_t key = keys[r];
-        if (key <= B || key == PREF_MARK) {
-            const uint32_t at = atomicAdd(count, 1u);
+    // (whole waves stay in the loop: the append is one atomic per wave)
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t r0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); r0 < n_rows; r0 += stride) {
+        const uint64_t r = r0 + (threadIdx.x & 63);
+        const uint32_t key = r < n_rows ? keys[r] : 0xFFFFFFFFu;
+        const bool take = r < n_rows && (key <= B || key == PREF_MARK);
+        const unsigned long long m = __ballot(take);
+        if (m == 0ull) continue;
+        uint32_t base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (take) {
+            const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
             if (at < cap) cand_rows[at] = (uint32_t)r;
         }
     }
 }
 
-// stage 2: the candidates' exact keys — RowAcc, row16_sum and the distance expression of knn_scan_kernel, one 16-lane
-// group per row.  *count > cap: nothing is computed and *fallback becomes 1.
+// stage 2: the candidates' exact distance keys — RowAcc, row16_sum and the distance expression of knn_scan_kernel, one
+// 16-lane group per row — into key32_out[c] beside cand_rows[c]; the k smallest (key, row) pairs are then found by the
+// radix select over those two arrays.  flags[0] = candidate count (in), flags[1] = fallback, flags[2] = go (out): more
+// candidates than cap => nothing is computed, fallback = 1, go = 0.
 template <int NCH>
 __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restrict__ table, const float* __restrict__ q,
-                                                          const uint32_t* __restrict__ cand_rows, const uint32_t* __restrict__ count,
-                                                          uint32_t cap, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ fallback) {
+                                                          const uint32_t* __restrict__ cand_rows, uint32_t* __restrict__ flags,
+                                                          uint32_t cap, uint32_t* __restrict__ key32_out) {
     constexpr int DIM = NCH * 64;
-    const uint32_t C = *count;
-    if (C > cap) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *fallback = 1u;
-        return;
+    const uint32_t C = flags[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        flags[1] = C > cap ? 1u : 0u;
+        flags[2] = C > cap ? 0u : 1u;
     }
+    if (C > cap) return;
     const int lane = threadIdx.x & 63, i = lane & 15;
     f32x4 qf[NCH];
 #pragma unroll
@@ -615,35 +639,10 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
         const f32x4* p = reinterpret_cast<const f32x4*>(table + (uint64_t)row * DIM) + i;
         RowAcc<NCH> a; a.zero();
 #pragma unroll
-        for (int t = 0; t < NCH; ++t) a.step(qf[t], p[16 * t]);
+        for (int t = 0; t < NCH; ++t) a.step(qf[t], __builtin_nontemporal_load(p + 16 * t));
         const float d = a.dot(), s = a.sumsq();
-        if (live && i == 0) keys_out[c0] = make_key(1.0f - d / (sq * sqrtf(s)), row);
+        if (live && i == 0) key32_out[c0] = dist_to_u32(1.0f - d / (sq * sqrtf(s)));
     }
-}
-
-// the k smallest of the (<= PREF_CAP) candidate keys, ascending, KEY_MAX behind them; nothing when *fallback is set.
-// One block, PREF_CAP * 8 bytes of dynamic LDS; the sort runs over the power of two that holds the candidates.
-__global__ __launch_bounds__(1024) void knn_topk_sort_kernel(const uint64_t* __restrict__ in, const uint32_t* __restrict__ count,
-                                                             const uint32_t* __restrict__ fallback, uint32_t k, uint64_t* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
-    if (*fallback) return;
-    const uint32_t n = min(*count, PREF_CAP);
-    int np = 64;
-    while ((uint32_t)np < n) np <<= 1;
-    for (int j = threadIdx.x; j < np; j += 1024) buf[j] = (uint32_t)j < n ? in[j] : KEY_MAX;
-    __syncthreads();
-    for (int kk = 2; kk <= np; kk <<= 1)
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int p = threadIdx.x; p < np / 2; p += 1024) {
-                const int a = ((p & ~(j - 1)) << 1) | (p & (j - 1)), b = a | j;
-                const uint64_t x = buf[a], y = buf[b];
-                const bool up = (a & kk) == 0;
-                if ((x > y) == up) { buf[a] = y; buf[b] = x; }
-            }
-            __syncthreads();
-        }
-    for (uint32_t j = threadIdx.x; j < k; j += 1024) out[j] = j < (uint32_t)np ? buf[j] : KEY_MAX;
 }
 
 // Q queries in one pass over the table (throughput variant).  Same per-row

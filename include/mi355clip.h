@@ -171,7 +171,7 @@ int mi_knn_set_base(mi_knn* t, uint64_t base);
 /* Options of a shard.  "prefilter" = 1: two-stage EXACT search for k <= 4096 on shards of >= 2^18 rows — a bf16 mirror of the
  * rows (+ 50 % device memory; built by the next search, kept up to date by every later one) is scanned first, the rows
  * within a data-independent error bound of the k-th coarse distance are re-evaluated from the fp32 rows with the
- * single-pass arithmetic: same ids, same distance bits, about half the bytes per query.  Corpora that put more than 16384
+ * single-pass arithmetic: same ids, same distance bits, about half the bytes per query.  Corpora that put more than 2^21
  * rows inside the bound fall back to the single pass on the device.  0 (default) frees the mirror. */
 int mi_knn_set_option(mi_knn* t, const char* key, int value);
 /* Of the most recent single-query search of this shard (waits for it): how many rows stage 2 re-evaluated, and whether the

@@ -94,8 +94,8 @@ def test_rows_at_the_worst_case_of_the_bf16_rounding(table):
         assert not fell_back and cand >= k, (k, cand, fell_back)
 
 
-def test_a_corpus_inside_the_error_band_falls_back_to_the_single_pass(built):
-    """every row within 2 eps of the k-th: more candidates than the buffer holds -> the gated single-pass scan answers"""
+def test_a_corpus_inside_the_error_band_is_re_evaluated_whole(built):
+    """every row within 2 eps of the k-th: stage 2 re-evaluates them all (the radix select over the candidates scales)"""
     rng = np.random.default_rng(5)
     base = rng.standard_normal(DIM).astype(np.float32)
     t = EmbeddingTable(DIM, 0)
@@ -108,15 +108,36 @@ def test_a_corpus_inside_the_error_band_falls_back_to_the_single_pass(built):
     for k in (1, 10, 64, 1000):
         _same(*_both(t, q, k))
         cand, fell_back = t.prefilter_stats()
-        assert fell_back and cand > 16384
+        assert not fell_back and cand == len(t)
     # and exact duplicates: ties must break by id on both paths
     t2 = EmbeddingTable(DIM, 0)
     for i in range(6):
         t2.insert(np.repeat(base[None, :], chunk, 0))
-    _same(*_both(t2, q, 10))
-    assert t2.knn(q, 10)[0].tolist() == list(range(10))
+    for k in (10, 1000):
+        _same(*_both(t2, q, k))
+        assert t2.knn(q, k)[0].tolist() == list(range(k))
     t.close()
     t2.close()
+
+
+def test_more_candidates_than_stage_two_accepts_fall_back_to_the_single_pass(built):
+    """2.3 M identical rows (> 2^21 candidates): the gated single pass answers, on the device, with the same bits"""
+    import torch
+    gen = torch.Generator(device="cuda"); gen.manual_seed(11)
+    base = torch.randn((DIM,), device="cuda", generator=gen)
+    t = EmbeddingTable(DIM, 0)
+    t.reserve(2_300_000)
+    x = base[None, :].repeat(100_000, 1).contiguous()  # exact duplicates: one coarse key for all of them
+    for i in range(23):
+        t.insert_device(x.data_ptr(), 100_000, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    q = (base + 0.01 * torch.randn((DIM,), device="cuda", generator=gen)).cpu().numpy()
+    for k in (10, 1000):
+        _same(*_both(t, q, k))
+        cand, fell_back = t.prefilter_stats()
+        assert fell_back and cand > (1 << 21), (k, cand, fell_back, len(t))
+        assert t.knn(q, k)[0].tolist() == list(range(k))  # ties by id
+    t.close()
 
 
 def test_sharded_table_forwards_the_option_and_stays_bit_identical(built):

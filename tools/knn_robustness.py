@@ -46,11 +46,13 @@ def fill(table, kind, n, q, gen):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--prefilter", action="store_true", help="also time the two-stage exact search and report its candidates")
+    ap.add_argument("--corpora", default="iid,descending,ascending,clusters,iid again")
     args = ap.parse_args()
     out = {"rows": args.rows, "dim": 768, "results": []}
     st = torch.cuda.Stream()
     torch.cuda.set_stream(st)
-    for kind in ("iid", "descending", "ascending", "clusters", "iid again"):
+    for kind in args.corpora.split(","):
         gen = torch.Generator(device="cuda"); gen.manual_seed(1234)
         q = torch.randn((768,), device="cuda", generator=gen)
         t = EmbeddingTable(768, 0)
@@ -71,6 +73,20 @@ def main():
             out["results"].append({"corpus": kind, "k": k, "ms_per_query": round(ms, 4),
                                    "GB_per_s": round(args.rows * 3072 / ms / 1e6, 1),
                                    "frac_of_8TBs": round(args.rows * 3072 / ms / 1e6 / 8000, 4)})
+            if args.prefilter:
+                ref_i, ref_d = di.clone(), dd.clone()
+                t.set_option("prefilter", 1)
+                for _ in range(2):
+                    t.knn_device(q.data_ptr(), 1, k, di.data_ptr(), dd.data_ptr(), st.cuda_stream)
+                e0.record(st)
+                for _ in range(10):
+                    t.knn_device(q.data_ptr(), 1, k, di.data_ptr(), dd.data_ptr(), st.cuda_stream)
+                e1.record(st); st.synchronize()
+                cand, fell_back = t.prefilter_stats()
+                out["results"][-1].update({"two_stage_ms_per_query": round(e0.elapsed_time(e1) / 10, 4), "rows_re_evaluated": cand,
+                                           "fell_back_to_single_pass": fell_back,
+                                           "same_ids_and_distance_bits": bool(torch.equal(ref_i, di) and torch.equal(ref_d.view(torch.int32), dd.view(torch.int32)))})
+                t.set_option("prefilter", 0)
             print(out["results"][-1], file=sys.stderr, flush=True)
         t.close()
     print(json.dumps(out, indent=1))
