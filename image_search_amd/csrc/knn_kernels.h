@@ -472,6 +472,9 @@ __global__ __launch_bounds__(1024) void knn_select_sort_kernel(const uint64_t* _
 // squared norm outside [1e-30, 1e30]) are marked in the mirror and are always candidates.  More candidates than the
 // buffer holds (2 M: a corpus with a fifth of its rows within 2 eps of the k-th) => the single-pass scan runs instead;
 // it is enqueued behind stage 2 either way and returns at once when it is not needed (no host round trip).
+#ifndef PREF_DEPTH
+#define PREF_DEPTH 3
+#endif
 constexpr uint32_t PREF_MARK = 0xFFFFFFFEu;  // coarse key of a marked row: no distance maps to it (NaN is 0xFFFFFFFF), it ranks behind every real one
 constexpr uint32_t PREF_CAP = 1u << 21;  // candidates stage 2 accepts (2 M rows = 6.4 GB of fp32 rows at dim 768: a fifth of a 10 M-row pass)
 
@@ -557,14 +560,15 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse_kernel(const uint16_t*
             const float d = row16_sum(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
             if (i == it) mydot = d;
         };
-        u32x4 xa[U], xb[U];
-        load_row(xa, row0);
-#pragma unroll 1
-        for (int it = 0; it < 16; it += 2) {
-            load_row(xb, row0 + it + 1);
-            reduce_row(xa, it);
-            load_row(xa, row0 + (it + 2 < 16 ? it + 2 : 15));
-            reduce_row(xb, it + 1);
+        // PREF_DEPTH row buffers: PREF_DEPTH - 1 rows of loads in flight while one is summed (rows of dim * 2 bytes are half
+        // the fp32 scan's: two buffers left 144 KB per CU in flight against its 288 KB)
+        u32x4 xr[PREF_DEPTH][U];
+#pragma unroll
+        for (int d = 0; d < PREF_DEPTH - 1; ++d) load_row(xr[d], row0 + d);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            if (it + PREF_DEPTH - 1 < 16) load_row(xr[(it + PREF_DEPTH - 1) % PREF_DEPTH], row0 + it + PREF_DEPTH - 1);
+            reduce_row(xr[it % PREF_DEPTH], it);
         }
         const uint64_t r = (tile << 6) + lane;
         if (r < n_rows) {
