@@ -155,6 +155,40 @@ def test_sharded_table_forwards_the_option_and_stays_bit_identical(built):
     st.close()
 
 
+@pytest.mark.parametrize("dim", [128, 256, 512, 1024])
+def test_other_row_widths(built, dim):
+    """every instantiation of the mirror / coarse / rescore kernels (dim / 64 in {2, 4, 8, 16}; 12 is the rest of this file)"""
+    import torch
+    gen = torch.Generator(device="cuda"); gen.manual_seed(dim)
+    t = EmbeddingTable(dim, 0)
+    n = 270_000
+    x = torch.randn((n, dim), device="cuda", generator=gen)
+    t.insert_device(x.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for j, k in enumerate((1, 10, 64, 300)):
+        q = torch.randn((dim,), device="cuda", generator=gen).cpu().numpy()
+        t.set_option("prefilter", 0)
+        a = t.knn(q, k)
+        t.set_option("prefilter", 1)
+        b = t.knn(q, k)
+        _same(a, b)
+        cand, fell_back = t.prefilter_stats()
+        assert not fell_back and cand >= k
+    t.close()
+
+
+def test_a_table_that_does_not_qualify_is_served_by_the_single_pass(built):
+    t = EmbeddingTable(64, 0)   # dim 64: rows of half a 256-byte bf16 chunk; the option is accepted, the search ignores it
+    t.insert_synthetic(1, 0, 300_000)
+    t.set_option("prefilter", 1)
+    q = np.random.default_rng(0).standard_normal(64).astype(np.float32)
+    a = t.knn(q, 10)
+    assert t.prefilter_stats() == (0, False)
+    t.set_option("prefilter", 0)
+    _same(a, t.knn(q, 10))
+    t.close()
+
+
 def test_option_errors(built):
     t = EmbeddingTable(DIM, 0)
     with pytest.raises(RuntimeError, match="unknown option"):
