@@ -10,9 +10,9 @@ server/src/search.rs:20-102) and read the k results back.  The H2D of the batch 
 the D2H of the results are INSIDE the timed region; the upload runs
 under the previous batch's tower, the scan is queued asynchronously but on the device it
 runs between two towers (step = tower + scan; measured) (mi_pipeline_*).
-The query runs as the two-stage EXACT search (a bf16 mirror of the rows prefilters, the fp32
-rows decide: ids and distance bits of the single pass; --no-prefilter = one
-pass over the fp32 rows, which is also what `roofline_knn` times).  With N > 1 ranks (one process per
+The query runs as the two-stage EXACT search (a byte mirror of the rows prefilters, the fp32
+rows decide: ids and distance bits of the single pass; --prefilter 1 = the bf16
+mirror, --no-prefilter = one pass over the fp32 rows, which is also what `roofline_knn` times).  With N > 1 ranks (one process per
 GPU) every rank embeds its own batch (replicas, no collective) and owns its own
 10M-row shard of an N x 10M table; the per-shard top-k are all-gathered over RCCL
 and merged on every rank — weak scaling.
@@ -103,7 +103,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the BASELINE config 1 / 2 sub-lines")
     ap.add_argument("--serial", action="store_true", help="A/B: synchronise after every step (no cross-step overlap)")
-    ap.add_argument("--no-prefilter", action="store_true", help="A/B: the query as ONE pass over the fp32 rows (no bf16 mirror)")
+    ap.add_argument("--no-prefilter", action="store_true", help="A/B: the query as ONE pass over the fp32 rows (no mirror)")
+    ap.add_argument("--prefilter", type=int, default=2, choices=(1, 2), help="mirror of the two-stage exact search: 2 = bytes (default), 1 = bf16")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
@@ -155,7 +156,7 @@ def main():
     table.reserve(args.rows + total_steps * args.batch)  # the appended rows never reallocate the table
     table.insert_synthetic(0, rank * args.rows, args.rows)
     if not args.no_prefilter:
-        table.set_option("prefilter", 1)  # the mirror is built by the first (warm-up) query and caught up by every later one
+        table.set_option("prefilter", args.prefilter)  # the mirror is built by the first (warm-up) query and caught up by every later one
     n_q = 64
     queries = synth.corpus_rows(1, 0, n_q)
     pipe = Pipeline(model, table)
@@ -243,7 +244,7 @@ def main():
         ms_knn = time_knn(table, args.k, 20)
         ms_knn_two, pref_cand, pref_fell_back = None, 0, False
         if not args.no_prefilter:
-            table.set_option("prefilter", 1)
+            table.set_option("prefilter", args.prefilter)
             ms_knn_two = time_knn(table, args.k, 20)
             pref_cand, pref_fell_back = table.prefilter_stats()
     pipe.close()
@@ -259,7 +260,7 @@ def main():
                                      "queries_per_sec": round(1e3 / ms, 1), "GB_per_s": round(3.072 / ms * 1e3, 1),
                                      "frac_of_hbm_peak": round(3.072 / ms * 1e3 / PEAK_HBM_GBS, 4)}
         if not args.no_prefilter:
-            t1m.set_option("prefilter", 1)
+            t1m.set_option("prefilter", args.prefilter)
             for k in (10, 1000):
                 ms = time_knn(t1m, k, 50)
                 extra[f"knn_1m_k{k}"]["two_stage_ms_per_query"] = round(ms, 4)
@@ -270,7 +271,7 @@ def main():
                                   "GB_per_s": round(rows_total * 3072 / ms / 1e6, 1),
                                   "frac_of_hbm_peak": round(rows_total * 3072 / ms / 1e6 / PEAK_HBM_GBS, 4)}
         if not args.no_prefilter:
-            table.set_option("prefilter", 1)
+            table.set_option("prefilter", args.prefilter)
             extra["knn_10m_k1000"]["two_stage_ms_per_query"] = round(time_knn(table, 1000, 10), 4)
             table.set_option("prefilter", 0)
         m32 = Model.from_file(wpath, local, PRECISION_F32)
@@ -318,8 +319,10 @@ def main():
                                    f"top-{args.k} query over {args.rows}+ x 768 fp32 rows per GPU -> D2H of the k results; fused on HIP "
                                    "streams (the upload runs under the previous batch's tower; the scan is asynchronous to the host and runs between towers)"
                                    + ("; query = ONE pass over the fp32 rows" if args.no_prefilter else
-                                      "; query = two-stage EXACT search: a bf16 mirror of the rows (+50 % HBM) prefilters, the rows within a "
-                                      "data-independent error bound of the k-th are re-evaluated from the fp32 rows: ids and distance bits of the single pass")
+                                      ("; query = two-stage EXACT search: a byte mirror of the rows with a per-row scale (+25 % HBM) prefilters, the rows a "
+                                       "rigorous per-row error bound cannot exclude" if args.prefilter == 2 else
+                                       "; query = two-stage EXACT search: a bf16 mirror of the rows (+50 % HBM) prefilters, the rows within a "
+                                       "data-independent error bound of the k-th") + " are re-evaluated from the fp32 rows: ids and distance bits of the single pass")
                                    + ("; --serial: no overlap" if args.serial else ""),
                        "batch": args.batch, "rows_per_gpu": args.rows, "k": args.k, "queries_per_step": 1,
                        "transfers_in_timed_region": True,
@@ -329,7 +332,8 @@ def main():
             "knn": {"queries_per_sec": round(1e3 / (ms_knn_two or ms_knn), 2), "ms_per_query": round(ms_knn_two or ms_knn, 4),
                     "ms_per_query_in_the_pipeline": round(ms_knn_overlapped, 4),
                     "ms_per_query_single_pass": round(ms_knn, 4),
-                    "mode": "single pass over the fp32 rows" if args.no_prefilter else "two-stage exact (bf16 mirror prefilter + fp32 re-evaluation)",
+                    "mode": "single pass over the fp32 rows" if args.no_prefilter else
+                            f"two-stage exact ({'byte' if args.prefilter == 2 else 'bf16'} mirror prefilter + fp32 re-evaluation)",
                     "rows_searched_per_sec": round(world * len(table) / ((ms_knn_two or ms_knn) * 1e-3), 0), "dtype": "f32"},
             "roofline": {"bound": "mfma", "kernel": "ViT-L/14 forward (gemm_bf16_pp_kernel x 96 + attention + LayerNorm, two half-chunk streams)",
                          "achieved": round(tf_exec, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -348,7 +352,8 @@ def main():
                              "note": "the single-pass scan over the fp32 rows: algorithmic bytes = rows x 768 x 4"},
         }
         if ms_knn_two:
-            two_bytes = len(table) * (768 * 2 + 4 + 4 * 5)  # mirror + stored norm + the coarse keys written once and read four times
+            row_bytes = 768 + 12 if args.prefilter == 2 else 768 * 2 + 4      # mirror row + its per-row floats
+            two_bytes = len(table) * (row_bytes + 4 * 5 + (4 if args.prefilter == 2 else 0))  # + the coarse keys written once and read four times (+ the bound factors in the collect)
             out["roofline_knn"]["two_stage"] = {
                 "ms_per_query": round(ms_knn_two, 4), "bytes_read_and_written": two_bytes,
                 "GB_per_s_of_those_bytes": round(two_bytes / (ms_knn_two * 1e-3) / 1e9, 1),

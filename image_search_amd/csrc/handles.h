@@ -97,9 +97,13 @@ struct mi_knn {
     size_t keys32_cap = 0, sel_cap = 0;
     // two-stage exact search (mi_knn_set_option "prefilter"): a bf16 copy of the rows + their squared norms, kept up to
     // `mirror_rows` and caught up by the next search; candidate rows / keys of stage 2
-    bool prefilter = false;
+    int prefilter = 0;              // 0 off, 1 bf16 mirror, 2 byte mirror
     bool last_prefiltered = false;  // the most recent single-query search went through the two stages
-    uint16_t* d_mirror = nullptr;
+    uint16_t* d_mirror = nullptr;   // bf16 rows (prefilter 1) or byte rows (prefilter 2: dim bytes per row)
+    float* d_scale8 = nullptr;      // prefilter 2: per-row scale, per-row bound factor, rho of the query in flight
+    float* d_cfac8 = nullptr;
+    float* d_rho8 = nullptr;
+    size_t scale8_cap = 0, cfac8_cap = 0, rho8_cap = 0;
     float* d_xx = nullptr;
     uint64_t mirror_rows = 0;
     size_t mirror_cap = 0, xx_cap = 0;

@@ -139,7 +139,8 @@ void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint
 // *fallback == 1: the caller enqueues the single pass behind it, gated by that word.
 constexpr uint64_t PREF_MIN_ROWS = 1u << 18;
 bool prefilter_applies(const mi_knn* t, uint32_t k) {
-    return t->prefilter && (k <= 64 || (k <= 4096 && t->select_path)) && t->dim % 128 == 0 && t->rows >= PREF_MIN_ROWS;
+    const uint32_t width = t->prefilter == 2 ? 256u : 128u;  // whole 256-byte chunks per mirror row
+    return t->prefilter && (k <= 64 || (k <= 4096 && t->select_path)) && t->dim % width == 0 && t->rows >= PREF_MIN_ROWS;
 }
 uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s) {
     ensure(t, (void**)&t->d_keys32, &t->keys32_cap, (size_t)t->cap, sizeof(uint32_t));
@@ -148,10 +149,17 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s)
     ensure(t, (void**)&t->d_pref_rows, &t->pref_rows_cap, (size_t)2 * PREF_CAP, sizeof(uint32_t));  // rows, then their exact keys
     ensure(t, (void**)&t->d_pref_keys, &t->pref_keys_cap, (size_t)4096, sizeof(uint64_t));
     ensure(t, (void**)&t->d_pref_flag, &t->pref_flag_cap, (size_t)4, sizeof(uint32_t));
-    if (t->mirror_cap < (size_t)t->cap * t->dim || t->xx_cap < (size_t)t->cap) t->mirror_rows = 0;  // (re)allocated below: rebuild
+    const bool bytes = t->prefilter == 2;
+    const size_t mirror_elems = bytes ? ((size_t)t->cap * t->dim + 1) / 2 : (size_t)t->cap * t->dim;  // in uint16 units
+    if (t->mirror_cap < mirror_elems || t->xx_cap < (size_t)t->cap || (bytes && t->scale8_cap < (size_t)t->cap)) t->mirror_rows = 0;  // (re)allocated below: rebuild
     t->mirror_rows = std::min(t->mirror_rows, t->rows);
-    ensure(t, (void**)&t->d_mirror, &t->mirror_cap, (size_t)t->cap * t->dim, sizeof(uint16_t));
+    ensure(t, (void**)&t->d_mirror, &t->mirror_cap, mirror_elems, sizeof(uint16_t));
     ensure(t, (void**)&t->d_xx, &t->xx_cap, (size_t)t->cap, sizeof(float));
+    if (bytes) {
+        ensure(t, (void**)&t->d_scale8, &t->scale8_cap, (size_t)t->cap, sizeof(float));
+        ensure(t, (void**)&t->d_cfac8, &t->cfac8_cap, (size_t)t->cap, sizeof(float));
+        ensure(t, (void**)&t->d_rho8, &t->rho8_cap, (size_t)4, sizeof(float));
+    }
     const uint64_t n_tiles = (t->rows + 63) / 64;
     const uint32_t blocks = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 4, (n_tiles + 3) / 4));
     const uint32_t hb = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 8, (t->rows + 255) / 256);
@@ -162,7 +170,34 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s)
     const size_t sel_bytes = ((size_t)6 * SEL_BINS + 64) * sizeof(uint32_t);
     HIP_CHECK(hipMemsetAsync(t->d_sel, 0, sel_bytes, s));
     HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), s));
-    const float eps = 0x1p-8f + 4.1f * (float)(t->dim + 8) * 0x1p-24f + 2e-6f;  // bf16: 8 significant bits, unit roundoff 2^-8
+    const float e0 = 4.1f * (float)(t->dim + 8) * 0x1p-24f + 2e-6f;  // fp32 summations, norms, divisions
+    const float eps = 0x1p-8f + e0;                                  // bf16: 8 significant bits, unit roundoff 2^-8
+    if (bytes) {
+        uint8_t* m8 = reinterpret_cast<uint8_t*>(t->d_mirror);
+        switch (t->dim / 64) {
+#define MI_CASE(NCH)                                                                                                     \
+    case NCH:                                                                                                            \
+        if (t->mirror_rows < t->rows) {                                                                                  \
+            const uint64_t todo = t->rows - t->mirror_rows;                                                              \
+            const uint32_t mb = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 8, (todo + 15) / 16);                   \
+            hipLaunchKernelGGL((knn_mirror8_kernel<NCH>), dim3(std::max(mb, 1u)), dim3(256), 0, s, t->table, t->mirror_rows, \
+                               t->rows, m8, t->d_xx, t->d_scale8, t->d_cfac8);                                           \
+            t->mirror_rows = t->rows;                                                                                    \
+        }                                                                                                                \
+        hipLaunchKernelGGL((knn_scan_coarse8_kernel<NCH>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8,      \
+                           t->d_cfac8, t->rows, d_q, e0, t->d_keys32, t->d_rho8);                                        \
+        for (int p = 0; p < 3; ++p)                                                                                      \
+            hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, p, t->d_sel, states); \
+        hipLaunchKernelGGL(knn_prefilter_collect8_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->d_cfac8, t->rows, k, \
+                           t->d_sel, states, t->d_rho8, e0, PREF_CAP, t->d_pref_rows, flags);                            \
+        hipLaunchKernelGGL((knn_rescore_kernel<NCH>), dim3(t->n_cu * 8), dim3(256), 0, s, t->table, d_q, t->d_pref_rows, \
+                           flags, PREF_CAP, key32);                                                                      \
+        break;
+            MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16)
+#undef MI_CASE
+            default: fail(MI_ERR_UNSUPPORTED, "dim %u: the byte prefilter is built for dim/64 in {4,8,12,16}", t->dim);
+        }
+    } else
     switch (t->dim / 64) {
 #define MI_CASE(NCH)                                                                                                     \
     case NCH:                                                                                                            \
@@ -352,7 +387,8 @@ void mi_knn_free(mi_knn* t) {
     if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
     for (void* p : {(void*)t->table, (void*)t->d_q, (void*)t->d_cand, (void*)t->d_tmp, (void*)t->d_keys,
                     (void*)t->d_idx, (void*)t->d_dist, (void*)t->d_keys32, (void*)t->d_sel, (void*)t->d_mirror,
-                    (void*)t->d_xx, (void*)t->d_pref_rows, (void*)t->d_pref_keys, (void*)t->d_pref_flag})
+                    (void*)t->d_xx, (void*)t->d_pref_rows, (void*)t->d_pref_keys, (void*)t->d_pref_flag, (void*)t->d_scale8,
+                    (void*)t->d_cfac8, (void*)t->d_rho8})
         if (p) (void)hipFree(p);
     delete t;
 }
@@ -363,17 +399,18 @@ int mi_knn_set_option(mi_knn* t, const char* key, int value) {
         std::lock_guard<std::mutex> l(t->mu);
         const std::string k(key);
         if (k == "prefilter") {
-            // two-stage exact search for k <= 64: a bf16 mirror of the rows (+ 50 % memory, built by the next search and
-            // kept up to date by every later one) prefilters, the fp32 rows decide; results are those of the single pass
-            if (value != 0 && value != 1) fail(MI_ERR_INVALID, "prefilter: 0 or 1 (got %d)", value);
-            t->prefilter = value != 0;
-            if (!t->prefilter && t->d_mirror) {
+            // two-stage exact search: a mirror of the rows (1: bf16, + 50 % memory; 2: bytes, + 25 %; built by the next search
+            // and kept up to date by every later one) prefilters, the fp32 rows decide; results are those of the single pass
+            if (value < 0 || value > 2) fail(MI_ERR_INVALID, "prefilter: 0, 1 or 2 (got %d)", value);
+            if (value != t->prefilter && t->d_mirror) {  // another form (or none): the mirror goes, the next search rebuilds
                 DeviceGuard g(t->device);
                 t->reads.sync();
-                HIP_CHECK(hipFree(t->d_mirror)); t->d_mirror = nullptr; t->mirror_cap = 0;
-                HIP_CHECK(hipFree(t->d_xx)); t->d_xx = nullptr; t->xx_cap = 0;
+                for (void** p : {(void**)&t->d_mirror, (void**)&t->d_xx, (void**)&t->d_scale8, (void**)&t->d_cfac8})
+                    if (*p) { HIP_CHECK(hipFree(*p)); *p = nullptr; }
+                t->mirror_cap = t->xx_cap = t->scale8_cap = t->cfac8_cap = 0;
                 t->mirror_rows = 0;
             }
+            t->prefilter = value;
         } else {
             fail(MI_ERR_INVALID, "unknown option '%s' (known: prefilter)", key);
         }

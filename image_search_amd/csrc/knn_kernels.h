@@ -470,13 +470,13 @@ __global__ __launch_bounds__(1024) void knn_select_sort_kernel(const uint64_t* _
 // eps = 2^-8 + 4.1 (dim + 8) 2^-24 + 2e-6 (4.10e-3 at dim 768), independent of the data; tests/test_prefilter_bound.py
 // drives rows built to sit at the rounding's worst case against it.  Rows the bound does not cover (a non-finite or > 3e38 element, a
 // squared norm outside [1e-30, 1e30]) are marked in the mirror and are always candidates.  More candidates than the
-// buffer holds (2 M: a corpus with a fifth of its rows within 2 eps of the k-th) => the single-pass scan runs instead;
+// buffer holds (4 M) => the single-pass scan runs instead;
 // it is enqueued behind stage 2 either way and returns at once when it is not needed (no host round trip).
 #ifndef PREF_DEPTH
 #define PREF_DEPTH 3
 #endif
 constexpr uint32_t PREF_MARK = 0xFFFFFFFEu;  // coarse key of a marked row: no distance maps to it (NaN is 0xFFFFFFFF), it ranks behind every real one
-constexpr uint32_t PREF_CAP = 1u << 21;  // candidates stage 2 accepts (2 M rows = 6.4 GB of fp32 rows at dim 768: a fifth of a 10 M-row pass)
+constexpr uint32_t PREF_CAP = 1u << 22;  // candidates stage 2 accepts (4 M rows = 12.9 GB of fp32 rows at dim 768: two fifths of a 10 M-row pass)
 
 // rows [first, end) of the table -> bf16 mirror rows + stored squared norms (-1 = "always a candidate")
 template <int NCH>
@@ -598,6 +598,182 @@ __global__ __launch_bounds__(256) void knn_prefilter_collect_kernel(const uint32
         const uint64_t r = r0 + (threadIdx.x & 63);
         const uint32_t key = r < n_rows ? keys[r] : 0xFFFFFFFFu;
         const bool take = r < n_rows && (key <= B || key == PREF_MARK);
+        const unsigned long long m = __ballot(take);
+        if (m == 0ull) continue;
+        uint32_t base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (take) {
+            const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (at < cap) cand_rows[at] = (uint32_t)r;
+        }
+    }
+}
+
+// ---- the 8-bit form of stage 1 ("prefilter" = 2): a quarter of the single pass's bytes ---------------------------------
+// Rows as unsigned bytes u_j = 128 + round(x_j * 127 / a), a = max_j |x_j| (so x^_j = s (u_j - 128), s = a / 127, and
+// |x^_j - x_j| <= s / 2), with three floats per row: the scale s, the squared norm, and c = 0.53 s / |x|.  The error of
+// the coarse cosine is bounded PER ROW and per query:  |q.x^ - q.x| <= (s / 2) |q|_1, i.e. on the cosine
+// eps_r = c_r * rho, rho = |q|_1 / |q|_2 (0.53 instead of 0.5: the fp32 summation of sum q_j u_j, whose terms are up to
+// 255 |q_j|, and the rounding of x_j * 127 / a), plus the same 4.1 (dim + 8) 2^-24 + 2e-6 as above.  The key stored per
+// row is the UPPER bound U_r = d~_r + eps_r: the k-th smallest of them bounds the exact k-th distance from above, and a
+// row can belong to the answer only if its LOWER bound U_r - 2 eps_r is not beyond it.  Random rows sit two orders of
+// magnitude inside this bound (their byte errors cancel), so the band is wide for what it needs to catch: ~10^2 (k = 10)
+// to ~10^4 (k = 1000) candidates on 10 M iid rows; stage 2 is the same as for the bf16 mirror.
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void knn_mirror8_kernel(const float* __restrict__ table, uint64_t first, uint64_t end,
+                                                          uint8_t* __restrict__ mirror, float* __restrict__ xx,
+                                                          float* __restrict__ scale, float* __restrict__ cfac) {
+    constexpr int DIM = NCH * 64;
+    const int lane = threadIdx.x & 63, i = lane & 15;
+    const uint64_t group = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4, n_groups = ((uint64_t)gridDim.x * 256) >> 4;
+    for (uint64_t r0 = first + group; r0 < ((end - first + n_groups - 1) / n_groups) * n_groups + first; r0 += n_groups) {
+        const bool live = r0 < end;
+        const uint64_t r = live ? r0 : end - 1;
+        const f32x4* p = reinterpret_cast<const f32x4*>(table + r * DIM) + i;
+        f32x4 v[NCH];
+        float s2 = 0.0f, a = 0.0f;
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            v[t] = p[16 * t];
+            const float e[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bad |= !(fabsf(e[j]) <= 3.0e38f);
+                s2 = __builtin_fmaf(e[j], e[j], s2);
+                a = fmaxf(a, fabsf(e[j]));
+            }
+        }
+        s2 = row16_sum(s2);
+        a = row16_max(a);
+        const unsigned long long bm = __ballot(bad);
+        const bool marked = ((bm >> (lane & 48)) & 0xFFFFull) != 0ull || !(s2 >= 1.0e-30f && s2 <= 1.0e30f);
+        const float inv = marked ? 0.0f : 127.0f / a, sc = a / 127.0f;
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            const float e[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q8 = (int)rintf(fminf(fmaxf(e[j] * inv, -127.0f), 127.0f)) + 128;
+                w |= (uint32_t)(q8 & 0xFF) << (8 * j);
+            }
+            if (live) *reinterpret_cast<uint32_t*>(mirror + r * DIM + 64 * t + 4 * i) = w;
+        }
+        if (live && i == 0) {
+            xx[r] = marked ? -1.0f : s2;
+            scale[r] = sc;
+            cfac[r] = marked ? 0.0f : 0.53f * sc / sqrtf(s2) * 1.000001f;
+        }
+    }
+}
+
+// stage 1 on the byte mirror: every row's UPPER-bound key (PREF_MARK for the marked rows).  Lane i of a 16-lane group
+// loads the 16 bytes at offset 256 u + 16 i of its row (dim a multiple of 256); rho_out[0] = rho for the collect pass.
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void knn_scan_coarse8_kernel(const uint8_t* __restrict__ mirror, const float* __restrict__ xx,
+                                                               const float* __restrict__ scale, const float* __restrict__ cfac,
+                                                               uint64_t n_rows, const float* __restrict__ q, float e0,
+                                                               uint32_t* __restrict__ all_keys, float* __restrict__ rho_out) {
+    static_assert(NCH % 4 == 0, "rows of whole 256-byte chunks of bytes");
+    constexpr int DIM = NCH * 64, U = NCH / 4;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const uint32_t wave = blockIdx.x * 4 + wib, n_waves = gridDim.x * 4;
+    float qf[U][16];
+    float sq, rho, qsum128;
+    {
+        float s2 = 0.0f, s1 = 0.0f, ss = 0.0f;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                qf[u][e] = q[256 * u + 16 * i + e];
+                s2 = __builtin_fmaf(qf[u][e], qf[u][e], s2);
+                s1 += fabsf(qf[u][e]);
+                ss += qf[u][e];
+            }
+        sq = sqrtf(row16_sum(s2));
+        rho = row16_sum(s1) / sq * 1.000001f;
+        qsum128 = 128.0f * row16_sum(ss);
+        if (blockIdx.x == 0 && threadIdx.x == 0) rho_out[0] = rho;
+    }
+    const uint64_t n_tiles = (n_rows + 63) >> 6;
+    auto load_row = [&](u32x4 (&x)[U], uint64_t r) {
+        r = r < n_rows ? r : n_rows - 1;
+        const u32x4* p = reinterpret_cast<const u32x4*>(mirror + r * DIM) + i;
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p + 16 * u);
+    };
+    for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
+        float mydot = 0.0f;
+        const uint64_t row0 = (tile << 6) + 16 * g;
+        auto reduce_row = [&](const u32x4 (&x)[U], int it) {
+            float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t w[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // v_cvt_f32_ubyte0..3: one conversion per byte
+                    a[0] = __builtin_fmaf(qf[u][4 * j + 0], (float)(w[j] & 0xFFu), a[0]);
+                    a[1] = __builtin_fmaf(qf[u][4 * j + 1], (float)((w[j] >> 8) & 0xFFu), a[1]);
+                    a[2] = __builtin_fmaf(qf[u][4 * j + 2], (float)((w[j] >> 16) & 0xFFu), a[2]);
+                    a[3] = __builtin_fmaf(qf[u][4 * j + 3], (float)(w[j] >> 24), a[3]);
+                }
+            }
+            const float d = row16_sum((a[0] + a[1]) + (a[2] + a[3]));
+            if (i == it) mydot = d;
+        };
+        u32x4 xr[4][U];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) load_row(xr[d], row0 + d);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            if (it + 3 < 16) load_row(xr[(it + 3) & 3], row0 + it + 3);
+            reduce_row(xr[it & 3], it);
+        }
+        const uint64_t r = (tile << 6) + lane;
+        if (r < n_rows) {
+            const float s = xx[r];
+            const float dot = scale[r] * (mydot - qsum128);
+            const float upper = (1.0f - dot / (sq * sqrtf(s))) + (cfac[r] * rho + e0);
+            all_keys[r] = s < 0.0f ? PREF_MARK : dist_to_u32(upper);
+        }
+    }
+}
+
+// the candidates of the 8-bit stage: rows whose LOWER bound U_r - 2 eps_r is not beyond the k-th smallest upper bound
+__global__ __launch_bounds__(256) void knn_prefilter_collect8_kernel(const uint32_t* __restrict__ keys, const float* __restrict__ cfac,
+                                                                     uint64_t n_rows, uint32_t k, const uint32_t* __restrict__ hist,
+                                                                     SelState* __restrict__ states, const float* __restrict__ rho_ptr,
+                                                                     float e0, uint32_t cap, uint32_t* __restrict__ cand_rows,
+                                                                     uint32_t* __restrict__ count) {
+    const SelState st = sel_advance(hist, states, 3, k, n_rows);
+    float tau = __uint_as_float(0x7F800000u);  // fewer rows than k, or a NaN at rank k: everything
+    if (n_rows >= k && st.fixed >= 1) {
+        const uint64_t T = st.prefix | ((1ull << sel_shift(st.fixed - 1)) - 1ull);
+        const uint32_t T32 = (uint32_t)(T >> 32);
+        const float t = u32_to_dist(T32);
+        if (T32 < PREF_MARK && t == t) tau = t + 2e-6f;
+    }
+    const float rho = rho_ptr[0];
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t r0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); r0 < n_rows; r0 += stride) {
+        const uint64_t r = r0 + (threadIdx.x & 63);
+        bool take = false;
+        if (r < n_rows) {
+            const uint32_t key = keys[r];
+            take = key == PREF_MARK || key == 0xFFFFFFFFu || !(u32_to_dist(key) - 2.0f * (cfac[r] * rho + e0) > tau);
+        }
         const unsigned long long m = __ballot(take);
         if (m == 0ull) continue;
         uint32_t base = 0;

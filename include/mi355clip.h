@@ -168,10 +168,11 @@ int mi_clip_embed_text(mi_clip* m, const int32_t* input_ids, size_t n, float* ou
 int mi_knn_create(uint32_t dim, int device, mi_knn** out);
 void mi_knn_free(mi_knn* t);
 int mi_knn_set_base(mi_knn* t, uint64_t base);
-/* Options of a shard.  "prefilter" = 1: two-stage EXACT search for k <= 4096 on shards of >= 2^18 rows — a bf16 mirror of the
- * rows (+ 50 % device memory; built by the next search, kept up to date by every later one) is scanned first, the rows
- * within a data-independent error bound of the k-th coarse distance are re-evaluated from the fp32 rows with the
- * single-pass arithmetic: same ids, same distance bits, about half the bytes per query.  Corpora that put more than 2^21
+/* Options of a shard.  "prefilter" = 1 or 2: two-stage EXACT search for k <= 4096 on shards of >= 2^18 rows — a mirror of the
+ * rows (1: bf16, + 50 % device memory, dim % 128 == 0; 2: bytes with a per-row scale, + 25 %, dim % 256 == 0; built by the
+ * next search, kept up to date by every later one) is scanned first, the rows that a rigorous error bound (1: data-
+ * independent; 2: per row and query) cannot exclude are re-evaluated from the fp32 rows with the single-pass arithmetic:
+ * same ids, same distance bits, a half (1) or a quarter (2) of the bytes per query.  Corpora that put more than 2^22
  * rows inside the bound fall back to the single pass on the device.  0 (default) frees the mirror. */
 int mi_knn_set_option(mi_knn* t, const char* key, int value);
 /* Of the most recent single-query search of this shard (waits for it): how many rows stage 2 re-evaluated, and whether the

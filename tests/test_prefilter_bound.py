@@ -53,3 +53,53 @@ def test_bf16_rounding_is_nearest_even():
     r = bf16_rne(x)
     assert np.all(np.abs(r - x) <= np.abs(x) * 2.0 ** -8)
     assert r[1] == np.float32(1.0) and r[2] == np.float32(1.0 + 2.0 ** -6)  # ties go to the even mantissa
+
+
+# ---- the byte mirror: per-row bound eps_r = c_r * rho + e0, c_r = 0.53 s / |x|, rho = |q|_1 / |q|_2 ---------------------------
+
+E0 = 4.1 * (DIM + 8) * 2.0 ** -24 + 2e-6
+
+
+def quantise(x):
+    a = np.float32(np.abs(x).max())
+    inv = np.float32(127.0) / a
+    u = np.rint(np.clip(x.astype(np.float32) * inv, -127, 127)).astype(np.int32) + 128
+    s = a / np.float32(127.0)
+    return u.astype(np.uint8), np.float32(s)
+
+
+def coarse8(q, u, s, xx):
+    q = q.astype(np.float32)
+    acc = np.float32(0)
+    for c in range(0, DIM, 64):
+        acc = np.float32(acc + np.dot(q[c:c + 64], u[c:c + 64].astype(np.float32)).astype(np.float32))
+    qsum128 = np.float32(128.0) * np.float32(q.sum(dtype=np.float32))
+    dot = np.float32(s * (acc - qsum128))
+    return np.float32(1) - dot / (np.sqrt(np.float32(np.dot(q, q))) * np.sqrt(np.float32(xx)))
+
+
+def test_byte_bound_holds_on_random_and_on_worst_case_rows():
+    rng = np.random.default_rng(1)
+    tightest = 0.0
+    for trial in range(300):
+        q = rng.standard_normal(DIM).astype(np.float32)
+        if trial % 3 == 0:
+            x = rng.standard_normal(DIM).astype(np.float32) * np.float32(10.0 ** rng.integers(-6, 7))
+        elif trial % 3 == 1:
+            x = (q + 0.05 * rng.standard_normal(DIM)).astype(np.float32)
+            x[rng.integers(DIM)] *= np.float32(50.0)   # one dominant element: the scale is set by it, everything else is coarse
+        else:
+            steps = rng.integers(-100, 101, DIM).astype(np.float32)
+            steps[0] = 127.0
+            x = steps + np.where(q > 0, 0.49, -0.49).astype(np.float32) * (1 if trial % 2 else -1)  # every element half a step off
+            x[0] = 127.0
+        u, s = quantise(x)
+        xx = float(np.dot(x.astype(np.float64), x.astype(np.float64)))
+        exact = float(cos_dist32(q, x))
+        coarse = float(coarse8(q, u, s, xx))
+        rho = float(np.abs(q).sum() / np.sqrt(np.dot(q.astype(np.float64), q.astype(np.float64))))
+        eps = 0.53 * float(s) / np.sqrt(xx) * rho + E0
+        err = abs(coarse - exact)
+        assert err <= eps, (trial, err, eps)
+        tightest = max(tightest, err / eps)
+    assert tightest > 0.85  # the constructed rows use most of the bound: it is not loose by construction

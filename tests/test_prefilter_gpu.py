@@ -10,10 +10,13 @@ DIM = 768
 N = 300_000  # above the 2^18-row threshold of the prefilter; 0.9 GB of fp32 rows
 
 
+MODE = 1  # which mirror the helpers switch on: 1 = bf16 (most of this file), 2 = bytes (the tests at the end)
+
+
 def _both(t, q, k):
     t.set_option("prefilter", 0)
     a = t.knn(q, k)
-    t.set_option("prefilter", 1)
+    t.set_option("prefilter", MODE)
     b = t.knn(q, k)
     return a, b
 
@@ -121,21 +124,21 @@ def test_a_corpus_inside_the_error_band_is_re_evaluated_whole(built):
 
 
 def test_more_candidates_than_stage_two_accepts_fall_back_to_the_single_pass(built):
-    """2.3 M identical rows (> 2^21 candidates): the gated single pass answers, on the device, with the same bits"""
+    """4.4 M identical rows (> 2^22 candidates): the gated single pass answers, on the device, with the same bits"""
     import torch
     gen = torch.Generator(device="cuda"); gen.manual_seed(11)
     base = torch.randn((DIM,), device="cuda", generator=gen)
     t = EmbeddingTable(DIM, 0)
-    t.reserve(2_300_000)
+    t.reserve(4_400_000)
     x = base[None, :].repeat(100_000, 1).contiguous()  # exact duplicates: one coarse key for all of them
-    for i in range(23):
+    for i in range(44):
         t.insert_device(x.data_ptr(), 100_000, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
     q = (base + 0.01 * torch.randn((DIM,), device="cuda", generator=gen)).cpu().numpy()
     for k in (10, 1000):
         _same(*_both(t, q, k))
         cand, fell_back = t.prefilter_stats()
-        assert fell_back and cand > (1 << 21), (k, cand, fell_back, len(t))
+        assert fell_back and cand > (1 << 22), (k, cand, fell_back, len(t))
         assert t.knn(q, k)[0].tolist() == list(range(k))  # ties by id
     t.close()
 
@@ -193,6 +196,81 @@ def test_option_errors(built):
     t = EmbeddingTable(DIM, 0)
     with pytest.raises(RuntimeError, match="unknown option"):
         t.set_option("nope", 1)
-    with pytest.raises(RuntimeError, match="0 or 1"):
-        t.set_option("prefilter", 2)
+    with pytest.raises(RuntimeError, match="0, 1 or 2"):
+        t.set_option("prefilter", 3)
+    t.close()
+
+
+# ---- the byte mirror ("prefilter" = 2): the same corpora, the per-row bound -----------------------------------------------------
+
+@pytest.fixture()
+def bytes_mode(monkeypatch):
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "MODE", 2)
+
+
+@pytest.mark.parametrize("k", [1, 10, 64, 1000])
+def test_bytes_random_corpus(table, bytes_mode, k):
+    rng = np.random.default_rng(100 + k)
+    for j in range(3):
+        q = rng.standard_normal(DIM).astype(np.float32)
+        if j == 2:
+            q = table.rows(54321, 1)[0].copy()
+        _same(*_both(table, q, k))
+        cand, fell_back = table.prefilter_stats()
+        assert not fell_back and cand >= k, (cand, fell_back)
+
+
+def test_bytes_rows_at_the_worst_case_of_the_quantisation(built, bytes_mode):
+    """every element half a quantisation step off, the direction chosen against (or for) the query: the coarse distance errs by
+    the whole per-row bound, exact neighbours hide behind decoys"""
+    rng = np.random.default_rng(16)
+    t = EmbeddingTable(DIM, 0)
+    t.insert_synthetic(21, 0, N)
+    q = rng.standard_normal(DIM).astype(np.float32)
+    n = 1500
+    steps = rng.integers(-100, 101, (2 * n, DIM)).astype(np.float32)
+    steps[:, 0] = 127.0                       # the row maximum: element 0 = 127 steps (scale = 1 step exactly)
+    half = np.where(np.sign(q)[None, :] > 0, 0.49, -0.49).astype(np.float32)
+    rows = np.concatenate([steps[:n] + half, steps[n:] - half])   # rounds to `steps`: dot too small / too large by sum |q_j| / 2
+    rows[:, 0] = 127.0
+    rows += (3.0 * q)[None, :]                # lean towards the query so that these rows are the neighbourhood
+    rows = rows[rng.permutation(2 * n)].astype(np.float32)
+    t.insert(rows)
+    for k in (1, 10, 64, 1000):
+        _same(*_both(t, q, k))
+        cand, fell_back = t.prefilter_stats()
+        assert not fell_back and cand >= k
+    t.close()
+
+
+def test_bytes_odd_rows_duplicates_and_appends(built, bytes_mode):
+    rng = np.random.default_rng(17)
+    t = EmbeddingTable(DIM, 0)
+    t.insert_synthetic(22, 0, N)
+    q = rng.standard_normal(DIM).astype(np.float32)
+    t.set_option("prefilter", 2)
+    t.knn(q, 5)                               # builds the mirror; what follows is caught up by later searches
+    odd = rng.standard_normal((7, DIM)).astype(np.float32)
+    odd[0, 5] = np.nan
+    odd[1, 9] = np.inf
+    odd[2] *= np.float32(3.2e38) / np.abs(odd[2]).max()
+    odd[3] = 0.0
+    odd[4] = q * np.float32(1e-17)
+    odd[5] = q * np.float32(1e19)
+    odd[6] = q
+    odd[6, 3] = 1e6                           # one dominant element: every other byte of the row is 128 +- 0
+    t.insert(odd)
+    t.insert(np.repeat(q[None, :] * np.float32(0.5), 3000, 0))  # 3 000 exact duplicates at distance ~0: ties by id
+    for k in (3, 64, 1000):
+        _same(*_both(t, q, k))
+    t.close()
+
+
+def test_bytes_narrow_rows_are_served_by_the_single_pass(built, bytes_mode):
+    t = EmbeddingTable(128, 0)                # 128 bytes per mirror row: not a whole 256-byte chunk
+    t.insert_synthetic(1, 0, 300_000)
+    q = np.random.default_rng(0).standard_normal(128).astype(np.float32)
+    _same(*_both(t, q, 10))
+    assert t.prefilter_stats() == (0, False)
     t.close()

@@ -46,7 +46,7 @@ def fill(table, kind, n, q, gen):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=10_000_000)
-    ap.add_argument("--prefilter", action="store_true", help="also time the two-stage exact search and report its candidates")
+    ap.add_argument("--prefilter", type=int, default=0, help="also time the two-stage exact search (1 = bf16 mirror, 2 = byte mirror) and report its candidates")
     ap.add_argument("--corpora", default="iid,descending,ascending,clusters,iid again")
     args = ap.parse_args()
     out = {"rows": args.rows, "dim": 768, "results": []}
@@ -75,7 +75,7 @@ def main():
                                    "frac_of_8TBs": round(args.rows * 3072 / ms / 1e6 / 8000, 4)})
             if args.prefilter:
                 ref_i, ref_d = di.clone(), dd.clone()
-                t.set_option("prefilter", 1)
+                t.set_option("prefilter", args.prefilter)
                 for _ in range(2):
                     t.knn_device(q.data_ptr(), 1, k, di.data_ptr(), dd.data_ptr(), st.cuda_stream)
                 e0.record(st)
