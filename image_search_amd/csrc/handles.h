@@ -103,7 +103,9 @@ struct mi_knn {
     float* d_scale8 = nullptr;      // prefilter 2: per-row scale, per-row bound factor, rho of the query in flight
     float* d_cfac8 = nullptr;
     float* d_rho8 = nullptr;
-    size_t scale8_cap = 0, cfac8_cap = 0, rho8_cap = 0;
+    float* d_g8 = nullptr;          // prefilter 2: per-dimension scale [dim] (+ [dim] accumulators), fixed once the first rows are mirrored
+    bool g8_ready = false;
+    size_t scale8_cap = 0, cfac8_cap = 0, rho8_cap = 0, g8_cap = 0;
     float* d_xx = nullptr;
     uint64_t mirror_rows = 0;
     size_t mirror_cap = 0, xx_cap = 0;

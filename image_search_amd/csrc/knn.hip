@@ -159,6 +159,17 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s)
         ensure(t, (void**)&t->d_scale8, &t->scale8_cap, (size_t)t->cap, sizeof(float));
         ensure(t, (void**)&t->d_cfac8, &t->cfac8_cap, (size_t)t->cap, sizeof(float));
         ensure(t, (void**)&t->d_rho8, &t->rho8_cap, (size_t)4, sizeof(float));
+        ensure(t, (void**)&t->d_g8, &t->g8_cap, (size_t)2 * t->dim, sizeof(float));
+        if (t->mirror_rows == 0) t->g8_ready = false;  // a rebuild may as well look at the rows again
+        if (!t->g8_ready) {  // the channel scales: RMS per dimension over the first rows (any positive values are correct)
+            const uint64_t sample = std::min<uint64_t>(t->rows, 1u << 16);
+            HIP_CHECK(hipMemsetAsync(t->d_g8 + t->dim, 0, t->dim * sizeof(float), s));
+            hipLaunchKernelGGL(knn_channel_sumsq_kernel, dim3(256), dim3(256), 0, s, t->table, sample, (int)t->dim, t->d_g8 + t->dim);
+            hipLaunchKernelGGL(knn_channel_scale_kernel, dim3((t->dim + 255) / 256), dim3(256), 0, s, t->d_g8 + t->dim, sample,
+                               (int)t->dim, t->d_g8);
+            t->g8_ready = true;
+            t->mirror_rows = 0;
+        }
     }
     const uint64_t n_tiles = (t->rows + 63) / 64;
     const uint32_t blocks = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 4, (n_tiles + 3) / 4));
@@ -181,11 +192,11 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s)
             const uint64_t todo = t->rows - t->mirror_rows;                                                              \
             const uint32_t mb = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 8, (todo + 15) / 16);                   \
             hipLaunchKernelGGL((knn_mirror8_kernel<NCH>), dim3(std::max(mb, 1u)), dim3(256), 0, s, t->table, t->mirror_rows, \
-                               t->rows, m8, t->d_xx, t->d_scale8, t->d_cfac8);                                           \
+                               t->rows, t->d_g8, m8, t->d_xx, t->d_scale8, t->d_cfac8);                                  \
             t->mirror_rows = t->rows;                                                                                    \
         }                                                                                                                \
         hipLaunchKernelGGL((knn_scan_coarse8_kernel<NCH>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8,      \
-                           t->d_cfac8, t->rows, d_q, e0, t->d_keys32, t->d_rho8);                                        \
+                           t->d_cfac8, t->d_g8, t->rows, d_q, e0, t->d_keys32, t->d_rho8);                               \
         for (int p = 0; p < 3; ++p)                                                                                      \
             hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, p, t->d_sel, states); \
         hipLaunchKernelGGL(knn_prefilter_collect8_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->d_cfac8, t->rows, k, \
@@ -388,7 +399,7 @@ void mi_knn_free(mi_knn* t) {
     for (void* p : {(void*)t->table, (void*)t->d_q, (void*)t->d_cand, (void*)t->d_tmp, (void*)t->d_keys,
                     (void*)t->d_idx, (void*)t->d_dist, (void*)t->d_keys32, (void*)t->d_sel, (void*)t->d_mirror,
                     (void*)t->d_xx, (void*)t->d_pref_rows, (void*)t->d_pref_keys, (void*)t->d_pref_flag, (void*)t->d_scale8,
-                    (void*)t->d_cfac8, (void*)t->d_rho8})
+                    (void*)t->d_cfac8, (void*)t->d_rho8, (void*)t->d_g8})
         if (p) (void)hipFree(p);
     delete t;
 }
@@ -409,6 +420,7 @@ int mi_knn_set_option(mi_knn* t, const char* key, int value) {
                     if (*p) { HIP_CHECK(hipFree(*p)); *p = nullptr; }
                 t->mirror_cap = t->xx_cap = t->scale8_cap = t->cfac8_cap = 0;
                 t->mirror_rows = 0;
+                t->g8_ready = false;
             }
             t->prefilter = value;
         } else {

@@ -620,6 +620,30 @@ __global__ __launch_bounds__(256) void knn_prefilter_collect_kernel(const uint32
 // row can belong to the answer only if its LOWER bound U_r - 2 eps_r is not beyond it.  Random rows sit two orders of
 // magnitude inside this bound (their byte errors cancel), so the band is wide for what it needs to catch: ~10^2 (k = 10)
 // to ~10^4 (k = 1000) candidates on 10 M iid rows; stage 2 is the same as for the bf16 mirror.
+// Channels are normalised first: x'_j = x_j / g_j with one g per dimension for the whole shard (the channel's RMS over the
+// first rows mirrored; any positive g is correct, it only decides how tight the bound is) and q'_j = q_j g_j, so that
+// q.x = q'.x'.  Without it a few dimensions two orders of magnitude above the rest — what trained CLIP embeddings have —
+// set every row's scale, the bytes of all other dimensions collapse around 128 and eps_r grows to 0.2 (measured: 46 % of
+// a 1 M-row corpus became candidates); with it a = max_j |x'_j|, rho = |q'|_1 / |q|_2 and the bound is back at a few 1e-3.
+__global__ __launch_bounds__(256) void knn_channel_sumsq_kernel(const float* __restrict__ table, uint64_t n_rows, int dim,
+                                                                float* __restrict__ acc) {
+    // rows blockIdx.x, + gridDim.x, ...; thread j owns channels j, j + 256, ... (coalesced across the block)
+    for (int c = threadIdx.x; c < dim; c += 256) {
+        float s = 0.0f;
+        for (uint64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+            const float v = table[r * dim + c];
+            if (fabsf(v) <= 1.0e18f) s = __builtin_fmaf(v, v, s);  // (non-finite and absurd values do not get a vote)
+        }
+        atomicAdd(&acc[c], s);
+    }
+}
+__global__ void knn_channel_scale_kernel(const float* __restrict__ acc, uint64_t n_rows, int dim, float* __restrict__ g) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= dim) return;
+    const float rms = sqrtf(acc[c] / (float)n_rows);
+    g[c] = (rms >= 1.0e-18f && rms <= 1.0e18f) ? rms : 1.0f;
+}
+
 __device__ __forceinline__ float row16_max(float v) {
     v = fmaxf(v, dpp_mov<0xB1>(v));
     v = fmaxf(v, dpp_mov<0x4E>(v));
@@ -630,11 +654,18 @@ __device__ __forceinline__ float row16_max(float v) {
 
 template <int NCH>
 __global__ __launch_bounds__(256) void knn_mirror8_kernel(const float* __restrict__ table, uint64_t first, uint64_t end,
-                                                          uint8_t* __restrict__ mirror, float* __restrict__ xx,
-                                                          float* __restrict__ scale, float* __restrict__ cfac) {
+                                                          const float* __restrict__ gch, uint8_t* __restrict__ mirror,
+                                                          float* __restrict__ xx, float* __restrict__ scale,
+                                                          float* __restrict__ cfac) {
     constexpr int DIM = NCH * 64;
     const int lane = threadIdx.x & 63, i = lane & 15;
     const uint64_t group = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4, n_groups = ((uint64_t)gridDim.x * 256) >> 4;
+    f32x4 ginv[NCH];  // 1 / g of this lane's channels
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gch + 64 * t + 4 * i);
+        ginv[t] = f32x4{1.0f / gv.x, 1.0f / gv.y, 1.0f / gv.z, 1.0f / gv.w};
+    }
     for (uint64_t r0 = first + group; r0 < ((end - first + n_groups - 1) / n_groups) * n_groups + first; r0 += n_groups) {
         const bool live = r0 < end;
         const uint64_t r = live ? r0 : end - 1;
@@ -649,15 +680,17 @@ __global__ __launch_bounds__(256) void knn_mirror8_kernel(const float* __restric
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 bad |= !(fabsf(e[j]) <= 3.0e38f);
-                s2 = __builtin_fmaf(e[j], e[j], s2);
-                a = fmaxf(a, fabsf(e[j]));
+                s2 = __builtin_fmaf(e[j], e[j], s2);  // the norm is the row's own: the cosine is
             }
+            v[t] = v[t] * ginv[t];                      // the bytes are the normalised channels'
+            a = fmaxf(a, fmaxf(fmaxf(fabsf(v[t].x), fabsf(v[t].y)), fmaxf(fabsf(v[t].z), fabsf(v[t].w))));
         }
         s2 = row16_sum(s2);
         a = row16_max(a);
+        bad |= !(a <= 3.0e38f && a >= 1.0e-30f);  // (a channel scale that does not fit this row)
         const unsigned long long bm = __ballot(bad);
         const bool marked = ((bm >> (lane & 48)) & 0xFFFFull) != 0ull || !(s2 >= 1.0e-30f && s2 <= 1.0e30f);
-        const float inv = marked ? 0.0f : 127.0f / a, sc = a / 127.0f;
+        const float inv = marked ? 0.0f : 127.0f / a, sc = marked ? 0.0f : a / 127.0f;
 #pragma unroll
         for (int t = 0; t < NCH; ++t) {
             const float e[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
@@ -682,7 +715,8 @@ __global__ __launch_bounds__(256) void knn_mirror8_kernel(const float* __restric
 template <int NCH>
 __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_kernel(const uint8_t* __restrict__ mirror, const float* __restrict__ xx,
                                                                const float* __restrict__ scale, const float* __restrict__ cfac,
-                                                               uint64_t n_rows, const float* __restrict__ q, float e0,
+                                                               const float* __restrict__ gch, uint64_t n_rows,
+                                                               const float* __restrict__ q, float e0,
                                                                uint32_t* __restrict__ all_keys, float* __restrict__ rho_out) {
     static_assert(NCH % 4 == 0, "rows of whole 256-byte chunks of bytes");
     constexpr int DIM = NCH * 64, U = NCH / 4;
@@ -697,8 +731,9 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_kernel(const uint8_t*
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                qf[u][e] = q[256 * u + 16 * i + e];
-                s2 = __builtin_fmaf(qf[u][e], qf[u][e], s2);
+                const float qe = q[256 * u + 16 * i + e];
+                s2 = __builtin_fmaf(qe, qe, s2);
+                qf[u][e] = qe * gch[256 * u + 16 * i + e];  // q' = q g: q.x = q'.x'
                 s1 += fabsf(qf[u][e]);
                 ss += qf[u][e];
             }
