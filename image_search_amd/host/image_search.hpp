@@ -81,6 +81,7 @@ class Model {
     ~Model() { mi_clip_free(h_); }
     uint32_t image() const { return info_[0]; }
     uint32_t proj() const { return info_[7]; }
+    mi_clip* handle() const { return h_; }
     // [n,3,H,W] f32 NCHW -> [n,proj] f32, flat (what `output.to_data()` + cast gives, clip.rs:120-124)
     std::vector<float> forward(const std::vector<float>& nchw, size_t n) const {
         if (nchw.size() != n * 3 * (size_t)image() * image()) throw std::runtime_error("input is not [n,3,H,W]");
@@ -127,6 +128,27 @@ class EmbeddingTable {
         return {idx, dist};
     }
     mi_knn* handle() const { return h_; }
+    // "prefilter" = 2 (bytes) or 1 (bf16): the two-stage exact search, same results from a quarter / a half of the bytes
+    void set_option(const std::string& key, int value) { check(mi_knn_set_option(h_, key.c_str(), value)); }
+};
+
+// the body of the scan loop and the query on HIP streams (BASELINE config 4)
+class Pipeline {
+    mi_pipeline* h_ = nullptr;
+
+   public:
+    Pipeline(clip_vit_large_patch14::Model& model, EmbeddingTable& table) { check(mi_pipeline_create(model.handle(), table.handle(), &h_)); }
+    Pipeline(const Pipeline&) = delete;
+    ~Pipeline() { mi_pipeline_free(h_); }
+    // [n,3,H,W] f32 (pinned memory from mi_host_alloc makes the upload asynchronous): returns the id of the first new row
+    uint64_t ingest(const float* nchw, size_t n) {
+        uint64_t first = 0;
+        check(mi_pipeline_ingest(h_, nchw, n, &first));
+        return first;
+    }
+    // results land in idx / dist when sync() (or drain) returns
+    void query(const float* q, uint32_t k, uint64_t* idx, float* dist) { check(mi_pipeline_query(h_, q, k, idx, dist)); }
+    void sync() { check(mi_pipeline_sync(h_)); }
 };
 
 // the whole table `image` {id, image_path, embedding} (server/src/search.rs:13-18) and the four statements the
