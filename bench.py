@@ -359,7 +359,8 @@ def main():
                 "GB_per_s_of_those_bytes": round(two_bytes / (ms_knn_two * 1e-3) / 1e9, 1),
                 "frac_of_hbm_peak_on_those_bytes": round(two_bytes / (ms_knn_two * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                 "speedup_over_single_pass": round(ms_knn / ms_knn_two, 3),
-                "rows_re_evaluated_last_query": pref_cand, "fell_back_to_single_pass": pref_fell_back}
+                "rows_re_evaluated_last_query": pref_cand, "fell_back_to_single_pass": pref_fell_back,
+                "traffic_stage1": pmc.get("knn_two_stage_stage1_hbm_bytes") if traffic_ok and args.prefilter == 2 else None}
         if extra:
             out["other_configs"] = extra
         if world == 1 and not args.no_cpu_baseline:
