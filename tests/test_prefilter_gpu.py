@@ -192,6 +192,43 @@ def test_a_table_that_does_not_qualify_is_served_by_the_single_pass(built):
     t.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_through_the_pipeline_rows_written_by_the_tower_reach_the_mirror(built, tmp_path, mode):
+    """mi_pipeline_ingest writes embeddings straight into the table on the ingest stream; the next query (search stream)
+    must mirror those rows before it scans: the chunk's own images are their own nearest neighbours, on both paths."""
+    from image_search_amd import synth
+    from image_search_amd.clip import PRECISION_F32, Model
+    from image_search_amd.search import Pipeline
+    cfg = synth.VitConfig(hidden=128, layers=2, heads=2, ff=512, patch=14, image=56, proj=256)
+    path = str(tmp_path / "small.safetensors")
+    synth.save_safetensors(synth.vit_weights(cfg, 5), path, {"num_attention_heads": cfg.heads})
+    m = Model.from_file(path, 0, PRECISION_F32)
+    t = EmbeddingTable(cfg.proj, 0)
+    t.reserve(270_000 + 64)
+    t.insert_synthetic(3, 0, 270_000)
+    t.set_option("prefilter", mode)
+    pipe = Pipeline(m, t)
+    px = synth.preprocess_rgb8(synth.images_u8(77, 16, cfg.image))
+    emb = m.forward(px)
+    results = []
+    for c in range(2):
+        first = pipe.ingest(px[8 * c:8 * c + 8])
+        assert first == 270_000 + 8 * c
+        results.append(pipe.query(emb[8 * c + 3], 5))       # one of the images just ingested: distance ~0 to its own row
+    pipe.sync()
+    for c, (ids, dist) in enumerate(results):
+        assert ids[0] == 270_000 + 8 * c + 3 and abs(float(dist[0])) < 1e-6
+        assert t.prefilter_stats()[1] is False
+    # and what the pipeline answered is what the single pass answers now
+    t.set_option("prefilter", 0)
+    for c, (ids, dist) in enumerate(results[-1:]):
+        a = t.knn(emb[8 + 3], 5)
+        assert np.array_equal(a[0], ids) and np.array_equal(a[1].view(np.uint32), dist.view(np.uint32))
+    pipe.close()
+    t.close()
+    m.close()
+
+
 def test_option_errors(built):
     t = EmbeddingTable(DIM, 0)
     with pytest.raises(RuntimeError, match="unknown option"):
