@@ -229,6 +229,25 @@ def test_through_the_pipeline_rows_written_by_the_tower_reach_the_mirror(built, 
     m.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_against_the_oracle_directly(built, orc, mode):
+    """not only equal to the single pass (which the other tests pin to the oracle): ids and distance bits of oracle/oracle.c"""
+    from image_search_amd import synth
+    from oracle.binding import orc_knn
+    n = 270_000
+    rows = synth.corpus_rows(31, 0, n)
+    t = EmbeddingTable(DIM, 0)
+    t.insert_synthetic(31, 0, n)
+    t.set_option("prefilter", mode)
+    for q in synth.corpus_rows(1031, 0, 2):
+        for k in (10, 1000):
+            gi, gd = t.knn(q, k)
+            oi, od = orc_knn(orc, q, rows, k)
+            assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+            assert t.prefilter_stats()[1] is False
+    t.close()
+
+
 def test_option_errors(built):
     t = EmbeddingTable(DIM, 0)
     with pytest.raises(RuntimeError, match="unknown option"):
