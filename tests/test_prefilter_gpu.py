@@ -149,11 +149,12 @@ def test_sharded_table_forwards_the_option_and_stays_bit_identical(built):
     one.insert_synthetic(9, 0, 3 * N)
     st = ShardedTable(DIM, [0, 0, 0], block_rows=4096)  # three shards of >= 2^18 rows each, on one device
     st.insert_synthetic(9, 0, 3 * N)
-    st.set_option("prefilter", 1)
     rng = np.random.default_rng(8)
-    for k in (10, 1000):
-        q = rng.standard_normal(DIM).astype(np.float32)
-        _same(one.knn(q, k), st.knn(q, k))
+    for mode in (1, 2):
+        st.set_option("prefilter", mode)
+        for k in (10, 1000):
+            q = rng.standard_normal(DIM).astype(np.float32)
+            _same(one.knn(q, k), st.knn(q, k))
     one.close()
     st.close()
 
