@@ -249,6 +249,24 @@ def test_against_the_oracle_directly(built, orc, mode):
     t.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_degenerate_queries_give_what_the_single_pass_gives(table, mode, monkeypatch):
+    """a zero query (0 / 0), a NaN in the query, an infinite one: every distance is NaN, the answer is rows 0 .. k-1 with NaN
+    distances on both paths (the coarse stage cannot exclude anything and says so)"""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "MODE", mode)
+    q0 = np.zeros(DIM, np.float32)
+    qn = np.random.default_rng(1).standard_normal(DIM).astype(np.float32)
+    qn[17] = np.nan
+    qi = np.random.default_rng(2).standard_normal(DIM).astype(np.float32)
+    qi[3] = np.inf
+    for q in (q0, qn, qi):
+        for k in (5, 1000):
+            a, b = _both(table, q, k)
+            _same(a, b)
+            assert np.isnan(b[1]).all() and b[0].tolist() == list(range(k))
+
+
 def test_option_errors(built):
     t = EmbeddingTable(DIM, 0)
     with pytest.raises(RuntimeError, match="unknown option"):
