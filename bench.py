@@ -12,13 +12,20 @@ under the previous batch's tower, the scan is queued asynchronously but on the d
 runs between two towers (step = tower + scan; measured) (mi_pipeline_*).
 The query runs as the two-stage EXACT search (a byte mirror of the rows prefilters, the fp32
 rows decide: ids and distance bits of the single pass; --prefilter 1 = the bf16
-mirror, --no-prefilter = one pass over the fp32 rows, which is also what `roofline_knn` times).  With N > 1 ranks (one process per
-GPU) every rank embeds its own batch (replicas, no collective) and owns its own
-10M-row shard of an N x 10M table; the per-shard top-k are all-gathered over RCCL
-and merged on every rank — weak scaling.
+mirror, --no-prefilter = one pass over the fp32 rows, which is also what `roofline_knn` times);
+the run itself checks that both modes return the same ids and distance bits (`two_stage_equal`).
+
+N > 1 (BASELINE config 5, one process per GPU): every rank embeds its own batch (replicas, no
+collective) and owns its own 10M-row shard of an N x 10M table; each query's per-shard top-k
+(12 k bytes) stays on the device, is all-gathered over RCCL in one collective and merged
+identically on every rank (image_search_amd.search.ShardExchange) — weak scaling.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` without a launcher starts its own N ranks (a child
+`python -m torch.distributed.run`, before anything here touches the GPU) and relays rank 0's line.
+When the box has fewer GPUs than ranks (a rehearsal) the ranks share GPU 0 and exchange over gloo.
 
 Rank 0 prints ONE JSON line.  `value` is whole-job images/s over the timed region
 (ViT + query); the per-phase rates (HIP events on the launch stream) are under
@@ -29,6 +36,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -48,51 +57,14 @@ VIT_FLOP_SKIPPED_PER_IMAGE = 2 * 256 * (2 * 1024 * 1024 + 2 * 1024 * 4096) + 4 *
 PEAK_BF16_TFLOPS = 2500.0                # dense bf16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0                    # HBM3E spec, same table
 PEAK_F32_TFLOPS = 157.3                  # exact-f32 MFMA, same table
+METRIC = "images/sec embedded (ViT-L/14 b=256) + queries/sec cosine top-10 over 10M x 768"
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(weights, cfg, orc_threads_hint):
-    """The oracle ("port") timed on this host's cores: a bounded sample of the same
-    workload.  Only this function and the parity tests touch oracle/."""
-    from image_search_amd import synth
-    from oracle import vit_numpy
-    from oracle.binding import load_oracle, orc_gen_f32, orc_knn
-
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # ViT: numpy fp32 restatement (BLAS threads = all cores): b = 1 (latency) and b = 8 (BASELINE.md §3
-    # planned b = 32; at < 1 image/s that alone would be > 40 s of a run that must finish in minutes)
-    px = synth.preprocess_rgb8(synth.images_u8(100, 8, cfg.image))
-    vit_numpy.vit_forward(weights, cfg, px[:1], np.float32)  # warm BLAS
-    t0 = time.perf_counter()
-    vit_numpy.vit_forward(weights, cfg, px[:1], np.float32)
-    t_one = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    vit_numpy.vit_forward(weights, cfg, px, np.float32)
-    t_vit = time.perf_counter() - t0
-    # kNN: C restatement (OpenMP), 1M x 768 rows, 5 queries
-    orc = load_oracle()
-    n = 1_000_000
-    rows = orc_gen_f32(orc, 0, 0, n * 768, 1.0).reshape(n, 768)
-    qs = synth.corpus_rows(1, 0, 5)
-    orc_knn(orc, qs[0], rows, 10)
-    t0 = time.perf_counter()
-    for q in qs:
-        orc_knn(orc, q, rows, 10)
-    t_knn = (time.perf_counter() - t0) / len(qs)
-    return {
-        "value": round(8 / t_vit, 3), "unit": "images/s", "cores": cores, "kind": "port",
-        "sample": "oracle/vit_numpy.py fp32 ViT-L/14, ONE batch of 8 images (numpy+BLAS, all cores; b=1 latency beside it); "
-                  "kNN below: oracle/oracle.c orc_knn (OpenMP) top-10 over 1M x 768, mean of 5 queries",
-        "vit_b1_seconds": round(t_one, 3), "vit_b8_seconds": round(t_vit, 3),
-        "knn": {"value": round(1.0 / t_knn, 2), "unit": "queries/s over 1M rows",
-                "equiv_10M": round(0.1 / t_knn, 3), "threads": int(orc.orc_threads())},
-    }
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -105,29 +77,186 @@ def main():
     ap.add_argument("--serial", action="store_true", help="A/B: synchronise after every step (no cross-step overlap)")
     ap.add_argument("--no-prefilter", action="store_true", help="A/B: the query as ONE pass over the fp32 rows (no mirror)")
     ap.add_argument("--prefilter", type=int, default=2, choices=(1, 2), help="mirror of the two-stage exact search: 2 = bytes (default), 1 = bf16")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for rehearsals)")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="auto", help="torch.distributed backend: nccl (== RCCL), gloo, or auto = nccl when every rank has "
+                                                      "its own GPU, gloo when ranks share one (rehearsals)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: launch, rendezvous, the exchange + merge over fake per-rank lists "
+                                                          "(what the CPU test of the self-launch path runs)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as a CHILD process (never an exec:
+    a process that has touched the GPU must not be replaced, and this one must not touch it at all), relay rank 0's
+    JSON line, return the child's exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    log(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in child.stdout:
+        if out.lstrip().startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        log("[bench] the ranks exited without a result line")
+        rc = 1
+    return rc
+
+
+def cpu_baseline(weights, cfg):
+    """The CPU side of the same workload, timed on this host's cores on a bounded sample.  "port": the oracle
+    (fixed summation orders: numpy ViT, OpenMP C kNN).  "library": the same two kernels as fast as torch-CPU runs
+    them (oracle/vit_torch.py: oneDNN / MKL GEMMs, fused attention, topk) — the CPU number someone would deploy.
+    Only this function and the parity tests touch oracle/."""
+    import torch
+
+    from image_search_amd import synth
+    from oracle import vit_numpy, vit_torch
+    from oracle.binding import load_oracle, orc_gen_f32, orc_knn
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # ViT: numpy fp32 restatement (BLAS threads = all cores): b = 1 (latency) and b = 8 (BASELINE.md §3
+    # planned b = 32; at < 1 image/s that alone would be > 40 s of a run that must finish in minutes)
+    px = synth.preprocess_rgb8(synth.images_u8(100, 32, cfg.image))
+    vit_numpy.vit_forward(weights, cfg, px[:1], np.float32)  # warm BLAS
+    t0 = time.perf_counter()
+    vit_numpy.vit_forward(weights, cfg, px[:1], np.float32)
+    t_one = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    vit_numpy.vit_forward(weights, cfg, px[:8], np.float32)
+    t_vit = time.perf_counter() - t0
+    # kNN: C restatement (OpenMP), 1M x 768 rows, 5 queries
+    orc = load_oracle()
+    n = 1_000_000
+    rows = orc_gen_f32(orc, 0, 0, n * 768, 1.0).reshape(n, 768)
+    qs = synth.corpus_rows(1, 0, 5)
+    orc_knn(orc, qs[0], rows, 10)
+    t0 = time.perf_counter()
+    for q in qs:
+        orc_knn(orc, q, rows, 10)
+    t_knn = (time.perf_counter() - t0) / len(qs)
+    out = {
+        "value": round(8 / t_vit, 3), "unit": "images/s", "cores": cores, "kind": "port",
+        "sample": "oracle/vit_numpy.py fp32 ViT-L/14, ONE batch of 8 images (numpy+BLAS, all cores; b=1 latency beside it); "
+                  "kNN below: oracle/oracle.c orc_knn (OpenMP) top-10 over 1M x 768, mean of 5 queries",
+        "vit_b1_seconds": round(t_one, 3), "vit_b8_seconds": round(t_vit, 3),
+        "knn": {"value": round(1.0 / t_knn, 2), "unit": "queries/s over 1M rows",
+                "equiv_10M": round(0.1 / t_knn, 3), "threads": int(orc.orc_threads())},
+    }
+    # the library-grade CPU point: torch, all cores
+    try:
+        threads = max(1, min(cores, 256))
+        torch.set_num_threads(threads)
+        W = vit_torch.load_weights(weights)
+        vit_torch.vit_forward(W, cfg, px[:8])  # warm
+        t0 = time.perf_counter()
+        vit_torch.vit_forward(W, cfg, px[:8])
+        t8 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ref32 = vit_torch.vit_forward(W, cfg, px)
+        t32 = time.perf_counter() - t0
+        port8 = vit_numpy.vit_forward(weights, cfg, px[:2], np.float32)
+        agree = float(np.abs(ref32[:2].numpy() - port8).max() / np.sqrt((port8 ** 2).mean()))
+        tr = torch.from_numpy(rows)
+        norms = tr.norm(dim=1)
+        tq = torch.from_numpy(qs)
+        ti, _ = vit_torch.knn(tr, norms, tq[0], 10)
+        oi, _ = orc_knn(orc, qs[0], rows, 10)
+        t0 = time.perf_counter()
+        for u in range(len(qs)):
+            vit_torch.knn(tr, norms, tq[u], 10)
+        tk = (time.perf_counter() - t0) / len(qs)
+        out["library"] = {
+            "kind": "library", "what": "oracle/vit_torch.py: torch-CPU fp32 (F.linear / scaled_dot_product_attention / topk), "
+                                       "library summation order", "threads": threads,
+            "vit_b8_images_per_sec": round(8 / t8, 2), "vit_b32_images_per_sec": round(32 / t32, 2),
+            "vit_b32_TFLOP_per_s": round(32 * VIT_FLOP_PER_IMAGE / t32 / 1e12, 3),
+            "vit_max_err_vs_port_over_rms": round(agree, 8),
+            "knn_1m_queries_per_sec": round(1.0 / tk, 2), "knn_equiv_10M_queries_per_sec": round(0.1 / tk, 3),
+            "knn_GB_per_s": round(n * 3072 / tk / 1e9, 1), "knn_top10_ids_equal_port": bool(np.array_equal(ti.numpy().astype(np.uint64), oi)),
+        }
+    except Exception as e:  # noqa: BLE001 — a baseline that cannot run must not take the GPU line with it
+        out["library"] = {"kind": "library", "error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def dry_run(args, world, rank):
+    """--dry-run: everything of the N-rank path that needs no GPU — launch, rendezvous, the packed all-gather and the
+    merge through the C ABI — over fake per-rank lists whose merged answer is known."""
+    import torch.distributed as dist
+
+    from image_search_amd.search import ShardExchange
+    if world > 1:
+        dist.init_process_group("gloo")
+    k = args.k
+    # rank r holds global ids r, r + world, r + 2 world, ... with distance id / 1000: merged top-k = ids 0..k-1
+    ids = (np.arange(k, dtype=np.uint64) * world + rank)
+    dd = (ids.astype(np.float32) / np.float32(1000.0)).astype(np.float32)
+    t0 = time.perf_counter()
+    ok = True
+    if world > 1:
+        ex = ShardExchange(k, depth=2)
+        for _ in range(args.warmup + args.steps):
+            ex.submit(ids, dd)
+            mi, md = ex.collect()
+            ok = ok and np.array_equal(mi, np.arange(k, dtype=np.uint64)) and \
+                np.array_equal(md, (np.arange(k, dtype=np.uint64).astype(np.float32) / np.float32(1000.0)))
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / max(1, args.steps + args.warmup) * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "dry_run": True,
+                          "exchange_ok": bool(ok), "config": {"workload": "dry run: launch + rendezvous + exchange + merge only (no GPU work)"}}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)  # nothing above imported torch or touched HIP
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    if args.dry_run:
+        return dry_run(args, world, rank)
 
     import torch
     import torch.distributed as dist
 
     from image_search_amd import synth
     from image_search_amd.clip import PRECISION_BF16, PRECISION_F32, Model
-    from image_search_amd.search import EmbeddingTable, PinnedBuffer, Pipeline, merge_candidates
+    from image_search_amd.search import EmbeddingTable, PinnedBuffer, Pipeline, ShardExchange
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    local = local % max(1, torch.cuda.device_count())  # rehearsal: several ranks may share one GPU
+    n_dev = max(1, torch.cuda.device_count())   # counting devices does not initialise the GPU
+    shared_gpu = world > n_dev                  # a rehearsal: several ranks on one GPU
+    backend = args.backend
+    if backend == "auto":
+        backend = "gloo" if shared_gpu else "nccl"   # RCCL refuses one GPU twice
+    local = local % n_dev
     torch.cuda.set_device(local)
     if world > 1:
-        if args.backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group(args.backend)
-    xdev = "cuda" if args.backend == "nccl" else "cpu"  # where the all-gather buffers live
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -160,44 +289,45 @@ def main():
     n_q = 64
     queries = synth.corpus_rows(1, 0, n_q)
     pipe = Pipeline(model, table)
-    g_idx = torch.empty((world, args.k), dtype=torch.int64, device=xdev)
-    g_dist = torch.empty((world, args.k), dtype=torch.float32, device=xdev)
-    merged = []
+    lag = 0 if args.serial else 1           # results of query i are consumed while query i+1 scans
+    ex = ShardExchange(args.k, depth=4) if world > 1 else None
+    merged, pending = [], []
 
-    def exchange(res):
-        """the one exchange step of the sharded search: 12*k bytes per rank and query"""
-        li = torch.from_numpy(res[0].view(np.int64)).to(xdev)
-        ld = torch.from_numpy(res[1]).to(xdev)
-        dist.all_gather_into_tensor(g_idx, li.reshape(1, -1))
-        dist.all_gather_into_tensor(g_dist, ld.reshape(1, -1))
-        merged.append(merge_candidates(g_idx.cpu().numpy().view(np.uint64), g_dist.cpu().numpy(), args.k))
-
-    pending = []
+    def consume(leave):
+        """host side of the exchange, `leave` queries behind the scan"""
+        if ex is None:
+            return
+        if not ex.on_device:
+            pipe.drain(leave)                # results of the older queries are on the host now
+            while len(pending) > leave:
+                ex.submit(*pending.pop(0))
+        while ex.in_flight() > (leave if ex.on_device else 0):
+            merged.append(ex.collect())
 
     def step(i):
         # BASELINE config 4: H2D of the batch -> bf16 tower -> rows appended on the device -> top-k over
         # table + appended rows -> D2H of the k results; the scan of step i runs on the search stream
-        # under the tower of step i+1 (mi_pipeline_*, include/mi355clip.h)
+        # (mi_pipeline_*, include/mi355clip.h).  N > 1: the k results stay on the device, are all-gathered
+        # (one collective of 12 k bytes per rank) and merged on every rank one step behind the scan.
         pipe.ingest(pins[i & 1].array)
-        pending.append(pipe.query(queries[i % n_q], args.k))
+        if ex is not None and ex.on_device:
+            ex.query(pipe, queries[i % n_q])
+        else:
+            pending.append(pipe.query(queries[i % n_q], args.k))
         if args.serial:
             pipe.sync()
-        if world > 1:
-            pipe.drain(0 if args.serial else 1)        # results of the previous query are on the host now
-            while len(pending) > (0 if args.serial else 1):
-                exchange(pending.pop(0))
+        consume(lag)
 
     def finish():
         pipe.sync()
-        if world > 1:
-            while pending:
-                exchange(pending.pop(0))
+        consume(0)
         pending.clear()
 
     for i in range(args.warmup):
         step(i)
     finish()
     pipe.stats(reset=True)
+    merged.clear()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -210,43 +340,62 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     n_f, ms_f, n_s, ms_s = pipe.stats()
     ms_vit = ms_f / max(n_f, 1)          # HIP events on the ingest stream around each forward, timed region only
     ms_knn_overlapped = ms_s / max(n_s, 1)
+    exchange_check = None
+    if world > 1:
+        # every rank must hold the same merged lists, each sorted and made of ids of all shards' ranges
+        mine = np.stack([np.concatenate([m[0].view(np.uint8), m[1].view(np.uint8)]) for m in merged]) if merged else np.zeros((0, 1), np.uint8)
+        g = [None] * world
+        dist.all_gather_object(g, mine.tobytes())
+        same = all(x == g[0] for x in g)
+        sorted_ok = all(bool(np.all(np.diff(m[1]) >= 0)) for m in merged)
+        exchange_check = {"queries_merged": len(merged), "identical_on_every_rank": bool(same), "sorted": bool(sorted_ok)}
+        if rank == 0 and not (same and sorted_ok and len(merged) == args.steps):
+            log(f"[bench] exchange check FAILED: {exchange_check}")
 
     extra = {}
+    two_stage_equal = None
     if rank == 0:
         # ---- the kNN kernel by itself (same table): HIP events on the launch stream --------------
         stream = torch.cuda.Stream()
         d_q = torch.from_numpy(queries).cuda()
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
 
-        def time_knn(tbl, k, reps):
-            d_i = torch.empty((1, k), dtype=torch.int64, device="cuda")
-            d_d = torch.empty((1, k), dtype=torch.float32, device="cuda")
-            for i in range(2):
-                tbl.knn_device(d_q[i].data_ptr(), 1, k, d_i.data_ptr(), d_d.data_ptr(), stream.cuda_stream)
+        def time_knn(tbl, k, reps, keep=0):
+            """ms per query; with keep > 0 also the (ids, distance bits) of the first `keep` queries"""
+            d_i = torch.empty((max(keep, 1), k), dtype=torch.int64, device="cuda")
+            d_d = torch.empty((max(keep, 1), k), dtype=torch.float32, device="cuda")
+            for i in range(max(2, keep)):
+                j = i if i < keep else 0
+                tbl.knn_device(d_q[i % n_q].data_ptr(), 1, k, d_i[j].data_ptr(), d_d[j].data_ptr(), stream.cuda_stream)
             stream.synchronize()
+            kept = (d_i.cpu().numpy().copy(), d_d.cpu().numpy().view(np.uint32).copy()) if keep else None
             a, b = ev(), ev()
             a.record(stream)
             for i in range(reps):
-                tbl.knn_device(d_q[i % n_q].data_ptr(), 1, k, d_i.data_ptr(), d_d.data_ptr(), stream.cuda_stream)
+                tbl.knn_device(d_q[i % n_q].data_ptr(), 1, k, d_i[0].data_ptr(), d_d[0].data_ptr(), stream.cuda_stream)
             b.record(stream)
             stream.synchronize()
-            return a.elapsed_time(b) / reps
+            ms = a.elapsed_time(b) / reps
+            return (ms, kept) if keep else ms
 
         # the single pass over the fp32 rows (the roofline kernel), then what the step actually ran
         table.set_option("prefilter", 0)
-        ms_knn = time_knn(table, args.k, 20)
+        ms_knn, ref_res = time_knn(table, args.k, 20, keep=16)
         ms_knn_two, pref_cand, pref_fell_back = None, 0, False
         if not args.no_prefilter:
             table.set_option("prefilter", args.prefilter)
-            ms_knn_two = time_knn(table, args.k, 20)
+            ms_knn_two, two_res = time_knn(table, args.k, 20, keep=16)
             pref_cand, pref_fell_back = table.prefilter_stats()
+            two_stage_equal = bool(np.array_equal(ref_res[0], two_res[0]) and np.array_equal(ref_res[1], two_res[1]))
+            if not two_stage_equal:
+                log("[bench] the two-stage search and the single pass DISAGREE on the timed queries")
     pipe.close()
 
     if rank == 0 and world == 1 and not args.no_extra_configs:
@@ -266,13 +415,17 @@ def main():
                 extra[f"knn_1m_k{k}"]["two_stage_ms_per_query"] = round(ms, 4)
         t1m.close()
         table.set_option("prefilter", 0)
-        ms = time_knn(table, 1000, 10)
+        ms, ref1000 = time_knn(table, 1000, 10, keep=4)
         extra["knn_10m_k1000"] = {"config": f"cosine top-1000 over {rows_total} x 768 f32 (the reference's K)", "ms_per_query": round(ms, 4),
                                   "GB_per_s": round(rows_total * 3072 / ms / 1e6, 1),
                                   "frac_of_hbm_peak": round(rows_total * 3072 / ms / 1e6 / PEAK_HBM_GBS, 4)}
         if not args.no_prefilter:
             table.set_option("prefilter", args.prefilter)
-            extra["knn_10m_k1000"]["two_stage_ms_per_query"] = round(time_knn(table, 1000, 10), 4)
+            ms, two1000 = time_knn(table, 1000, 10, keep=4)
+            extra["knn_10m_k1000"]["two_stage_ms_per_query"] = round(ms, 4)
+            eq = bool(np.array_equal(ref1000[0], two1000[0]) and np.array_equal(ref1000[1], two1000[1]))
+            extra["knn_10m_k1000"]["two_stage_equal"] = eq
+            two_stage_equal = bool(two_stage_equal and eq)
             table.set_option("prefilter", 0)
         m32 = Model.from_file(wpath, local, PRECISION_F32)
         d_img = torch.from_numpy(np.ascontiguousarray(pins[0].array[:32])).cuda()
@@ -293,6 +446,7 @@ def main():
                                  "frac_of_f32_mfma_peak": round(tf / PEAK_F32_TFLOPS, 4)}
         m32.close()
 
+    failed = False
     if rank == 0:
         imgs = world * args.batch * args.steps
         executed = VIT_FLOP_PER_IMAGE - VIT_FLOP_SKIPPED_PER_IMAGE
@@ -307,7 +461,7 @@ def main():
             pass
         traffic_ok = bool(pmc) and pmc.get("rows") == args.rows and pmc.get("batch") == args.batch
         out = {
-            "metric": "images/sec embedded (ViT-L/14 b=256) + queries/sec cosine top-10 over 10M x 768",
+            "metric": METRIC,
             "value": round(imgs / elapsed, 2),
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -323,10 +477,13 @@ def main():
                                        "rigorous per-row error bound cannot exclude" if args.prefilter == 2 else
                                        "; query = two-stage EXACT search: a bf16 mirror of the rows (+50 % HBM) prefilters, the rows within a "
                                        "data-independent error bound of the k-th") + " are re-evaluated from the fp32 rows: ids and distance bits of the single pass")
+                                   + (f"; BASELINE config 5 shape: {world} ranks x {args.rows} rows, per-shard top-k all-gathered ({backend}) and merged on every rank"
+                                      if world > 1 else "")
                                    + ("; --serial: no overlap" if args.serial else ""),
                        "batch": args.batch, "rows_per_gpu": args.rows, "k": args.k, "queries_per_step": 1,
                        "transfers_in_timed_region": True,
-                       "sharding": "ViT replicas; table row-sharded, all-gather of per-shard top-k"},
+                       "sharding": "ViT replicas; table row-sharded, all-gather of per-shard top-k",
+                       "backend": backend if world > 1 else None, "ranks_share_one_gpu": bool(shared_gpu)},
             "vit": {"images_per_sec": round(world * args.batch / (ms_vit * 1e-3), 1), "ms_per_batch": round(ms_vit, 3),
                     "note": "HIP events on the ingest stream around each forward of the timed region (one forward at a time on the ingest stream)"},
             "knn": {"queries_per_sec": round(1e3 / (ms_knn_two or ms_knn), 2), "ms_per_query": round(ms_knn_two or ms_knn, 4),
@@ -334,6 +491,7 @@ def main():
                     "ms_per_query_single_pass": round(ms_knn, 4),
                     "mode": "single pass over the fp32 rows" if args.no_prefilter else
                             f"two-stage exact ({'byte' if args.prefilter == 2 else 'bf16'} mirror prefilter + fp32 re-evaluation)",
+                    "two_stage_equal": two_stage_equal, "fell_back": bool(pref_fell_back),
                     "rows_searched_per_sec": round(world * len(table) / ((ms_knn_two or ms_knn) * 1e-3), 0), "dtype": "f32"},
             "roofline": {"bound": "mfma", "kernel": "ViT-L/14 forward (gemm_bf16_pp_kernel x 96 + attention + LayerNorm, two half-chunk streams)",
                          "achieved": round(tf_exec, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -360,11 +518,17 @@ def main():
                 "frac_of_hbm_peak_on_those_bytes": round(two_bytes / (ms_knn_two * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                 "speedup_over_single_pass": round(ms_knn / ms_knn_two, 3),
                 "rows_re_evaluated_last_query": pref_cand, "fell_back_to_single_pass": pref_fell_back,
+                "equal_to_single_pass": two_stage_equal,
                 "traffic_stage1": pmc.get("knn_two_stage_stage1_hbm_bytes") if traffic_ok and args.prefilter == 2 else None}
+        if exchange_check is not None:
+            out["exchange"] = exchange_check
+            failed = failed or not (exchange_check["identical_on_every_rank"] and exchange_check["sorted"]
+                                    and exchange_check["queries_merged"] == args.steps)
         if extra:
             out["other_configs"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(weights, cfg, None)
+            out["cpu_baseline"] = cpu_baseline(weights, cfg)
+        failed = failed or two_stage_equal is False
         print(json.dumps(out), flush=True)
 
     model.close()
@@ -372,8 +536,10 @@ def main():
     for pb in pins:
         pb.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 1 if failed else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -86,6 +86,8 @@ SYMBOLS = {
     "mi_index_save": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
     "mi_index_load": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
     "mi_knn_merge": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
+    "mi_knn_merge_device": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp]),
+    "mi_pipeline_query_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, c_vp, c_vp, c_vp]),
     "mi_pipeline_create": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
     "mi_pipeline_free": (None, [c_vp]),
     "mi_pipeline_ingest": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_u64p]),

@@ -68,7 +68,7 @@ extern "C" {
 
 const char* mi_last_error(void) { return g_last_error.c_str(); }
 
-int mi_abi_version(void) { return 3; }
+int mi_abi_version(void) { return 4; }
 
 int mi_device_count(void) {
     int n = 0;

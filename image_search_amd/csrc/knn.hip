@@ -671,6 +671,22 @@ int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint3
     });
 }
 
+// The merge every rank runs on what the all-gather left it, on the device: in = [lists][nq][k].
+int mi_knn_merge_device(int device, const uint64_t* d_idx_in, const float* d_dist_in, uint32_t lists, uint32_t nq, uint32_t k,
+                        uint64_t* d_idx, float* d_dist, void* stream) {
+    return guarded([&] {
+        if (k == 0) fail(MI_ERR_INVALID, "k must be >= 1");
+        if (nq == 0) return;
+        if (!d_idx || !d_dist || (lists && (!d_idx_in || !d_dist_in))) fail(MI_ERR_INVALID, "null argument");
+        if ((uint64_t)lists * k > 0xFFFFFFFFull || nq > 65535) fail(MI_ERR_UNSUPPORTED, "lists * k or nq too large");
+        DeviceGuard g(device);
+        const uint32_t threads = std::max<uint32_t>(lists * k, k);
+        hipLaunchKernelGGL(knn_merge_lists_kernel, dim3((threads + 255) / 256, nq), dim3(256), 0, (hipStream_t)stream, d_idx_in,
+                           d_dist_in, lists, k, (size_t)nq * k, d_idx, d_dist);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
 int mi_knn_search(mi_knn* t, const float* q, uint32_t nq, uint32_t k, uint64_t* idx, float* dist) {
     return guarded([&] {
         check_search_args(t, q, nq, k, idx, dist);

@@ -1088,6 +1088,65 @@ __global__ void knn_finalize_kernel(const uint64_t* __restrict__ keys, uint32_t 
     }
 }
 
+// ---- merge of per-shard result lists on the device (mi_knn_merge_device) ---------------
+// in: [lists][nq][k] (id, distance) entries, every list ascending by (dist_to_u32(distance), id) with its
+// MI_KNN_NO_ID padding at the tail — what each rank holds after the all-gather.  One thread per entry: its place in
+// the merged order is its own position plus, per other list, the number of entries in front of it (a binary search;
+// equal entries of two lists keep list order), so nothing is sorted and any lists * k fits.  Same result as
+// mi::merge_lists (core.hip).
+__device__ __forceinline__ bool merge_less(uint32_t ka, uint64_t ia, uint32_t kb, uint64_t ib) {
+    return ka < kb || (ka == kb && ia < ib);
+}
+__global__ __launch_bounds__(256) void knn_merge_lists_kernel(const uint64_t* __restrict__ idx_in, const float* __restrict__ dist_in,
+                                                              uint32_t lists, uint32_t k, size_t list_stride,
+                                                              uint64_t* __restrict__ idx, float* __restrict__ dist) {
+    const uint32_t u = blockIdx.y;  // query
+    const uint64_t* qi = idx_in + (size_t)u * k;
+    const float* qd = dist_in + (size_t)u * k;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < k) {  // slots behind the last real entry: "none"
+        uint32_t valid = 0;
+        for (uint32_t l = 0; l < lists; ++l) {
+            const uint64_t* li = qi + l * list_stride;
+            uint32_t lo = 0, hi = k;  // first NO_ID of the list
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (li[mid] != MI_KNN_NO_ID) lo = mid + 1; else hi = mid;
+            }
+            valid += lo;
+        }
+        if (e >= valid) {
+            idx[(size_t)u * k + e] = MI_KNN_NO_ID;
+            dist[(size_t)u * k + e] = __uint_as_float(0x7F800000u);
+        }
+    }
+    if (e >= lists * k) return;
+    const uint32_t l = e / k, p = e % k;
+    const uint64_t id = qi[l * list_stride + p];
+    if (id == MI_KNN_NO_ID) return;
+    const float d = qd[l * list_stride + p];
+    const uint32_t key = dist_to_u32(d);
+    uint32_t rank = p;
+    for (uint32_t o = 0; o < lists && rank < k; ++o) {
+        if (o == l) continue;
+        const uint64_t* li = qi + o * list_stride;
+        const float* ld = qd + o * list_stride;
+        uint32_t lo = 0, hi = k;  // entries of list o in front of this one
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint64_t mi_ = li[mid];
+            const uint32_t mk = dist_to_u32(ld[mid]);
+            const bool front = mi_ != MI_KNN_NO_ID && (o < l ? !merge_less(key, id, mk, mi_) : merge_less(mk, mi_, key, id));
+            if (front) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+    }
+    if (rank < k) {
+        idx[(size_t)u * k + rank] = id;
+        dist[(size_t)u * k + rank] = d;
+    }
+}
+
 // ---- seeded corpus generator (image_search_amd/synth.py gen_f32, bit for bit) ---------
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

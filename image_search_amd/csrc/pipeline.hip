@@ -63,8 +63,10 @@ namespace {
 void deliver(QuerySlot& s) {
     if (!s.busy) return;
     HIP_CHECK(hipEventSynchronize(s.done));
-    std::memcpy(s.user_idx, s.h_idx, (size_t)s.k * sizeof(uint64_t));
-    std::memcpy(s.user_dist, s.h_dist, (size_t)s.k * sizeof(float));
+    if (s.user_idx) {  // a query whose results stay on the device (mi_pipeline_query_device) has nothing to hand over
+        std::memcpy(s.user_idx, s.h_idx, (size_t)s.k * sizeof(uint64_t));
+        std::memcpy(s.user_dist, s.h_dist, (size_t)s.k * sizeof(float));
+    }
     s.busy = false;
 }
 
@@ -244,6 +246,36 @@ int mi_pipeline_query(mi_pipeline* p, const float* q, uint32_t k, uint64_t* idx,
         HIP_CHECK(hipMemcpyAsync(s.h_idx, s.d_idx, (size_t)k * 8, hipMemcpyDeviceToHost, p->search));
         HIP_CHECK(hipMemcpyAsync(s.h_dist, s.d_dist, (size_t)k * 4, hipMemcpyDeviceToHost, p->search));
         HIP_CHECK(hipEventRecord(s.done, p->search));
+        s.busy = true;
+    });
+}
+
+// The same query with its k results left on the device: the per-shard list a multi-GPU caller hands to the
+// all-gather (one process per GPU: torch.distributed / RCCL on `consumer_stream`) without a trip through the host.
+int mi_pipeline_query_device(mi_pipeline* p, const float* q, uint32_t k, uint64_t* d_idx, float* d_dist, void* consumer_stream) {
+    return guarded([&] {
+        if (!p) fail(MI_ERR_INVALID, "null pipeline handle");
+        if (!q || !d_idx || !d_dist) fail(MI_ERR_INVALID, "null query/result pointer");
+        if (k == 0) fail(MI_ERR_INVALID, "k must be >= 1");
+        std::lock_guard<std::mutex> lp(p->mu);
+        mi_knn* t = p->t;
+        std::lock_guard<std::mutex> l(t->mu);
+        DeviceGuard g(p->device);
+        QuerySlot& s = p->slots[p->next_slot];
+        p->next_slot = (p->next_slot + 1) % N_SLOTS;
+        deliver(s);
+        slot_reserve(s, t->dim, 0);  // only the query's staging buffers
+        std::memcpy(s.h_q, q, (size_t)t->dim * 4);
+        s.k = k; s.user_idx = nullptr; s.user_dist = nullptr;
+        HIP_CHECK(hipMemcpyAsync(s.d_q, s.h_q, (size_t)t->dim * 4, hipMemcpyHostToDevice, p->search));
+        t->writes.begin(p->search);
+        t->reads.begin(p->search);
+        auto& sp = span_begin(p, 1, p->search);
+        knn_search_one(t, s.d_q, k, d_idx, d_dist, p->search);
+        span_end(sp, p->search);
+        t->reads.end(p->search);
+        HIP_CHECK(hipEventRecord(s.done, p->search));
+        if (consumer_stream) HIP_CHECK(hipStreamWaitEvent((hipStream_t)consumer_stream, s.done, 0));
         s.busy = true;
     });
 }

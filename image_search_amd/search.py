@@ -187,6 +187,12 @@ class Pipeline:
         self._pending.append((idx, dist))  # the library writes into them at sync: keep them alive
         return idx, dist
 
+    def query_device(self, reference: np.ndarray, k: int, d_idx: int, d_dist: int, consumer_stream: int = 0):
+        """The same query, its k results left on the device at d_idx [k] uint64 / d_dist [k] f32 (mi_pipeline_query_device);
+        `consumer_stream` (a raw hipStream_t) is made to wait for them: the list a sharded search feeds to the all-gather."""
+        q = _f32(reference).reshape(-1)
+        check(lib().mi_pipeline_query_device(self._h, q.ctypes.data, k, d_idx, d_dist, consumer_stream))
+
     def sync(self):
         check(lib().mi_pipeline_sync(self._h))
         self._pending = []
@@ -215,6 +221,12 @@ def merge_candidates(idx_lists: np.ndarray, dist_lists: np.ndarray, k: int):
     dist = np.empty(k, np.float32)
     check(lib().mi_knn_merge(i.ctypes.data, d.ctypes.data, i.size // k, k, idx.ctypes.data, dist.ctypes.data))
     return idx, dist
+
+
+def merge_candidates_device(device: int, d_idx_in: int, d_dist_in: int, lists: int, nq: int, k: int, d_idx: int, d_dist: int,
+                            stream: int = 0):
+    """mi_knn_merge_device: the merge of the all-gathered [lists][nq][k] lists on the device, asynchronous on `stream`."""
+    check(lib().mi_knn_merge_device(device, d_idx_in, d_dist_in, lists, nq, k, d_idx, d_dist, stream))
 
 
 class ShardedTable:
@@ -311,6 +323,88 @@ def gather_and_merge(local_idx: np.ndarray, local_dist: np.ndarray, k: int, grou
     for u in range(nq):
         out_i[u], out_d[u] = merge_candidates(gi[:, u, :], gd[:, u, :], k)
     return out_i, out_d
+
+
+class ShardExchange:
+    """The one exchange step of the row-sharded search, one process per GPU: every rank's k results
+    — packed as k uint64 ids followed by k f32 distances, 12 k bytes — all-gathered in ONE collective and merged
+    identically on every rank (mi_knn_merge).
+      nccl (= RCCL over xGMI): the scan writes its list into a device buffer (Pipeline.query_device), the collective and the
+          readback of the gathered lists are enqueued behind it on torch's current stream; the host never touches the
+          per-rank list and blocks only in `collect`, for the oldest exchange.
+      gloo (CPU rehearsals and tests): the lists come from the host results of Pipeline.query / EmbeddingTable.knn.
+    `depth` exchanges may be in flight (a ring of buffers)."""
+
+    def __init__(self, k: int, device=None, group=None, depth: int = 4):
+        import torch
+        import torch.distributed as dist
+        self.k, self.group, self.depth = k, group, depth
+        self.world = dist.get_world_size(group)
+        self.on_device = dist.get_backend(group) == "nccl"
+        self.nbytes = 12 * k
+        dev = (device if device is not None else torch.device("cuda", torch.cuda.current_device())) if self.on_device else "cpu"
+        self.ring = []
+        for _ in range(depth):
+            slot = {"loc": torch.empty((1, self.nbytes), dtype=torch.uint8, device=dev),
+                    "all": torch.empty((self.world, self.nbytes), dtype=torch.uint8, device=dev), "busy": False}
+            if self.on_device:
+                slot["host"] = torch.empty((self.world, self.nbytes), dtype=torch.uint8).pin_memory()
+                slot["ev"] = torch.cuda.Event()
+            self.ring.append(slot)
+        self.n = 0
+        self.pending = []
+
+    def _slot(self):
+        slot = self.ring[self.n % self.depth]
+        self.n += 1
+        if slot["busy"]:
+            raise RuntimeError(f"more than {self.depth} exchanges in flight: collect() first")
+        slot["busy"] = True
+        self.pending.append(slot)
+        return slot
+
+    def _gather(self, slot):
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(slot["all"], slot["loc"], group=self.group)
+
+    def query(self, pipeline: "Pipeline", reference: np.ndarray):
+        """nccl only: enqueue the scan on the pipeline's search stream, the all-gather and the readback behind it."""
+        import torch
+        assert self.on_device, "ShardExchange.query needs the nccl backend; use submit() with host lists on gloo"
+        slot = self._slot()
+        p = slot["loc"].data_ptr()
+        pipeline.query_device(reference, self.k, p, p + 8 * self.k, torch.cuda.current_stream().cuda_stream)
+        self._gather(slot)
+        slot["host"].copy_(slot["all"], non_blocking=True)
+        slot["ev"].record()
+
+    def submit(self, local_idx: np.ndarray, local_dist: np.ndarray):
+        """A rank's list already on the host (gloo; or nccl after a host search): pack, all-gather."""
+        import torch
+        slot = self._slot()
+        packed = np.concatenate([np.ascontiguousarray(local_idx, np.uint64).reshape(self.k).view(np.uint8),
+                                 np.ascontiguousarray(local_dist, np.float32).reshape(self.k).view(np.uint8)])
+        slot["loc"].copy_(torch.from_numpy(packed).reshape(1, -1))
+        self._gather(slot)
+        if self.on_device:
+            slot["host"].copy_(slot["all"], non_blocking=True)
+            slot["ev"].record()
+
+    def collect(self):
+        """Oldest exchange in flight -> (ids [k], distances [k]) of the whole table; blocks for that one only."""
+        slot = self.pending.pop(0)
+        if self.on_device:
+            slot["ev"].synchronize()
+            h = slot["host"].numpy()
+        else:
+            h = slot["all"].numpy()
+        gi = np.ascontiguousarray(h[:, :8 * self.k]).view(np.uint64)
+        gd = np.ascontiguousarray(h[:, 8 * self.k:]).view(np.float32)
+        slot["busy"] = False
+        return merge_candidates(gi, gd, self.k)
+
+    def in_flight(self) -> int:
+        return len(self.pending)
 
 
 def _cstrs(strings):

@@ -256,6 +256,11 @@ int mi_knn_sharded_id(uint32_t block_rows, uint32_t n_shards, uint32_t shard, ui
  * global top-k under the same ordering.  Host-only. */
 int mi_knn_merge(const uint64_t* idx_in, const float* dist_in, uint32_t lists, uint32_t k,
                  uint64_t* idx, float* dist);
+/* The same merge on the device, asynchronous on `stream`: in = [lists][nq][k] (the rank-major buffer an all-gather of
+ * per-shard [nq][k] results leaves on every rank), out = [nq][k].  Each input list must be in result order with its
+ * MI_KNN_NO_ID padding at the tail (what every search entry point returns).  Bit-identical to mi_knn_merge. */
+int mi_knn_merge_device(int device, const uint64_t* d_idx_in, const float* d_dist_in, uint32_t lists, uint32_t nq, uint32_t k,
+                        uint64_t* d_idx, float* d_dist, void* stream);
 
 /* ------------------------------------------- fused flow (BASELINE config 4, one GPU) */
 
@@ -287,6 +292,11 @@ int mi_pipeline_ingest(mi_pipeline* p, const float* nchw, size_t n, uint64_t* fi
  * mi_pipeline_sync returns (or when 16 later queries have been enqueued).  Same results and
  * ordering as mi_knn_search. */
 int mi_pipeline_query(mi_pipeline* p, const float* q, uint32_t k, uint64_t* idx, float* dist);
+/* As mi_pipeline_query, the k results left on the device (d_idx [k] uint64, d_dist [k] f32, caller-owned, same device):
+ * the per-shard list of a row-sharded table, ready for the all-gather without a trip through the host.  The scan runs
+ * on the pipeline's search stream; `consumer_stream` (a hipStream_t, may be NULL) is made to wait for it — an event, no
+ * host block — so work enqueued on that stream afterwards (the collective) sees the results. */
+int mi_pipeline_query_device(mi_pipeline* p, const float* q, uint32_t k, uint64_t* d_idx, float* d_dist, void* consumer_stream);
 /* Wait for everything enqueued and deliver the pending query results. */
 int mi_pipeline_sync(mi_pipeline* p);
 /* Deliver finished queries, oldest first, until at most `leave_pending` are still pending (blocks

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(mi):
     for name in sorted(declared):
         assert hasattr(mi, name), f"{name} declared in include/ but not exported"
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
-    assert mi.mi_abi_version() == 3
+    assert mi.mi_abi_version() == 4
 
 
 def test_no_gpu_means_loud_failure_not_fallback(mi):

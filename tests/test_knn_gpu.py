@@ -203,7 +203,26 @@ def test_full_size_10m_matches_oracle_and_properties(built, orc):
         x.close()
     # whole-corpus oracle (host RAM: 30.7 GB)
     rows = orc_gen_f32(orc, 0, 0, n * 768).reshape(n, 768)
-    for (gi, gd), q in zip(res[:2], qs[:2]):
-        oi, od = orc_knn(orc, q, rows, 10)
-        _same(gi, gd, oi, od)
+    want = {}
+    for u, q in enumerate(qs[:2]):
+        for k in (10, 1000):
+            want[u, k] = orc_knn(orc, q, rows, k)
+    del rows
+    for u, (gi, gd) in enumerate(res[:2]):
+        _same(gi, gd, *want[u, 10])
+    # the query modes bench.py runs, at bench.py's size: the two-stage exact search over the bf16 (1) and the byte (2)
+    # mirror must return the oracle's ids and distance bits — through the two stages, not through the fallback
+    # (candidate counts, uint32 row ids and the 2^22-entry candidate buffer are only stressed at this size)
+    for mode in (1, 2):
+        t.set_option("prefilter", mode)
+        for u, q in enumerate(qs[:2]):
+            for k in (10, 1000):
+                gi, gd = t.knn(q, k)
+                cand, fell_back = t.prefilter_stats()
+                _same(gi, gd, *want[u, k])
+                assert k <= cand < (1 << 22) and not fell_back, (mode, k, cand, fell_back)
+    # ... and the single pass at the reference's K
+    t.set_option("prefilter", 0)
+    gi, gd = t.knn(qs[0], 1000)
+    _same(gi, gd, *want[0, 1000])
     t.close()

@@ -25,7 +25,8 @@ from oracle.binding import orc_knn
 pytestmark = pytest.mark.gpu
 
 SEL = [0, 127, 128, 255]
-N0 = 200_000  # rows already in the table (oracle-sized; the 10 M case is covered by properties in test_knn_gpu.py)
+N0 = 300_000  # rows already in the table: oracle-sized, and above the 2^18 rows from which the two-stage search applies
+              # (the 10 M case is in test_knn_gpu.py::test_full_size_10m_matches_oracle_and_properties)
 
 
 def close(out, ref, tol):
@@ -44,7 +45,10 @@ def l14_batch(built, tmp_path_factory):
     return cfg, path, px, ref
 
 
-def test_config4_batch256_bf16_embed_append_query(l14_batch, orc):
+@pytest.mark.parametrize("prefilter", [0, 2])
+def test_config4_batch256_bf16_embed_append_query(l14_batch, orc, prefilter):
+    """prefilter = 2 is the query mode bench.py runs (the two-stage exact search over the byte mirror): the same
+    oracle answers, and the two stages — not the fallback — must have produced them."""
     cfg, path, px, ref = l14_batch
     # the fp32 HIP path on the same four images: the parity path at 1e-4
     m32 = Model.from_file(path, 0, PRECISION_F32)
@@ -57,6 +61,8 @@ def test_config4_batch256_bf16_embed_append_query(l14_batch, orc):
     t = EmbeddingTable(768, 0)
     t.reserve(N0 + 3 * 256)
     t.insert_synthetic(7, 0, N0)
+    if prefilter:
+        t.set_option("prefilter", prefilter)
     base_rows = synth.corpus_rows(7, 0, N0)
     pipe = Pipeline(m, t)
     pin = [PinnedBuffer(px.shape), PinnedBuffer(px.shape)]
@@ -75,6 +81,11 @@ def test_config4_batch256_bf16_embed_append_query(l14_batch, orc):
     assert pipe.ingest(pin[0].array[:0]) == N0 + 552  # n = 0: no-op (clip.rs:112-118)
     pipe.sync()
     assert len(t) == N0 + 552
+    cand, fell_back = t.prefilter_stats()             # of the last query (k = 1000)
+    if prefilter:
+        assert cand >= 1000 and not fell_back, (cand, fell_back)
+    else:
+        assert cand == 0 and not fell_back
 
     rows = t.rows(N0, 552)
     ok, err = close(rows[SEL], ref, 3e-2)             # bf16 bound at the benchmarked shape, vs the oracle
