@@ -61,6 +61,11 @@ SYMBOLS = {
     "mi_knn_sharded_reserve": (ctypes.c_int, [c_vp, ctypes.c_uint64]),
     "mi_knn_sharded_set_option": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
     "mi_knn_sharded_append": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint64, c_u64p]),
+    "mi_knn_sharded_append_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint64, ctypes.c_int, c_vp, c_u64p]),
+    "mi_knn_sharded_shard": (c_vp, [c_vp, ctypes.c_uint32]),
+    "mi_knn_sharded_search_async": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
+    "mi_knn_sharded_sync": (ctypes.c_int, [c_vp]),
+    "mi_knn_sharded_rebalance": (ctypes.c_int, [c_vp, c_vp]),
     "mi_knn_sharded_append_synthetic": (ctypes.c_int, [c_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]),
     "mi_knn_sharded_get_rows": (ctypes.c_int, [c_vp, ctypes.c_uint64, ctypes.c_uint64, c_vp]),
     "mi_knn_sharded_search": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
@@ -89,6 +94,7 @@ SYMBOLS = {
     "mi_knn_merge_device": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp]),
     "mi_pipeline_query_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, c_vp, c_vp, c_vp]),
     "mi_pipeline_create": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
+    "mi_pipeline_create_sharded": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.c_int, c_vp, ctypes.POINTER(c_vp)]),
     "mi_pipeline_free": (None, [c_vp]),
     "mi_pipeline_ingest": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_u64p]),
     "mi_pipeline_query": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint32, c_vp, c_vp]),

@@ -122,6 +122,64 @@ struct mi_knn {
 };
 
 
+// The table row-sharded over several GPUs inside one process (sharded.hip).  Global row r lives in block r / block, block b
+// on shard b % n at local block b / n; every shard is an ordinary mi_knn whose kernels emit global ids (IdMap).
+typedef struct ncclComm* ncclComm_t;
+namespace mi {
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t b) {  // caller has the device selected and nothing in flight that uses the old buffer
+        if (b <= cap) return;
+        if (p) HIP_CHECK(hipFree(p));
+        p = nullptr; cap = 0;
+        HIP_CHECK(hipMalloc(&p, b));
+        cap = b;
+    }
+};
+struct PinnedBuf2 {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t b) {
+        if (b <= cap) return;
+        if (p) HIP_CHECK(hipHostFree(p));
+        p = nullptr; cap = 0;
+        HIP_CHECK(hipHostMalloc(&p, b, hipHostMallocDefault));
+        cap = b;
+    }
+};
+// one search in flight on a sharded table: per-shard query / result buffers, the gathered lists and the merged result
+// on the first shard's device, pinned copies for the host, and where the caller wants them
+struct ShardedSlot {
+    std::vector<DevBuf> d_q, d_idx, d_dist;   // [shard]
+    std::vector<DevBuf> g_idx, g_dist;        // [shard] (RCCL receive side) or [0] only (copy transport)
+    DevBuf m_idx, m_dist;                     // merged, on shard 0's device
+    PinnedBuf2 h_q, h_idx, h_dist;
+    std::vector<hipEvent_t> ev;               // [shard]: list of shard s is in place
+    hipEvent_t done = nullptr;
+    uint32_t nq = 0, k = 0;
+    uint64_t* user_idx = nullptr;
+    float* user_dist = nullptr;
+    bool busy = false;
+};
+}  // namespace mi
+
+struct mi_knn_sharded {
+    static constexpr int N_SLOTS = 8;
+    uint32_t dim = 0, block = 0;
+    uint64_t rows = 0;
+    std::vector<int> devices;
+    std::vector<mi_knn*> shard;
+    mi::ShardedSlot slots[N_SLOTS];
+    int next_slot = 0;
+    std::vector<ncclComm_t> comms;
+    bool use_rccl = false;
+    uint64_t generation = 0;                  // of the files last saved or loaded (mi_knn_sharded_save)
+    std::vector<hipEvent_t> ev_src;           // [device ordinal]: the peer copies of the last append_device from that device
+    std::mutex mu;
+    uint32_t n() const { return (uint32_t)shard.size(); }
+};
+
 namespace mi {
 // vit.hip
 hipStream_t clip_own_stream(mi_clip* m);
@@ -132,4 +190,12 @@ void clip_forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStr
 hipStream_t knn_own_stream(mi_knn* t);
 void knn_grow(mi_knn* t, uint64_t want_rows);       // may reallocate: waits for the handle's pending work
 void knn_search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s);
+void knn_truncate(mi_knn* t, uint64_t rows);        // forget the rows behind `rows` (a failed multi-shard append / load rolls back)
+void knn_merge_lists_device(const uint64_t* d_idx_in, const float* d_dist_in, uint32_t lists, uint32_t nq, uint32_t k,
+                            uint64_t* d_idx, float* d_dist, hipStream_t s);   // caller has the device selected
+// sharded.hip
+void sharded_place(const mi_knn_sharded* t, uint64_t r, uint32_t* s, uint64_t* local);
+uint64_t sharded_rows_of(const mi_knn_sharded* t, uint64_t total, uint32_t s);  // rows shard s holds when the table holds `total`
+void sharded_search_enqueue(mi_knn_sharded* t, const float* q, uint32_t nq, uint32_t k, uint64_t* idx, float* dist);  // t->mu held
+void sharded_deliver_all(mi_knn_sharded* t);                                    // t->mu held
 }  // namespace mi

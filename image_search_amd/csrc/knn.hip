@@ -368,6 +368,19 @@ void knn_grow(mi_knn* t, uint64_t want_rows) { grow(t, want_rows); }
 void knn_search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
     search_one(t, d_q, k, d_idx, d_dist, s);
 }
+void knn_truncate(mi_knn* t, uint64_t rows) {
+    std::lock_guard<std::mutex> l(t->mu);
+    if (rows >= t->rows) return;
+    t->rows = rows;
+    t->mirror_rows = std::min(t->mirror_rows, rows);
+}
+void knn_merge_lists_device(const uint64_t* d_idx_in, const float* d_dist_in, uint32_t lists, uint32_t nq, uint32_t k,
+                            uint64_t* d_idx, float* d_dist, hipStream_t s) {
+    const uint32_t threads = std::max<uint32_t>(lists * k, k);
+    hipLaunchKernelGGL(knn_merge_lists_kernel, dim3((threads + 255) / 256, nq), dim3(256), 0, s, d_idx_in, d_dist_in, lists, k,
+                       (size_t)nq * k, d_idx, d_dist);
+    HIP_CHECK(hipGetLastError());
+}
 }  // namespace mi
 
 extern "C" {
@@ -680,10 +693,7 @@ int mi_knn_merge_device(int device, const uint64_t* d_idx_in, const float* d_dis
         if (!d_idx || !d_dist || (lists && (!d_idx_in || !d_dist_in))) fail(MI_ERR_INVALID, "null argument");
         if ((uint64_t)lists * k > 0xFFFFFFFFull || nq > 65535) fail(MI_ERR_UNSUPPORTED, "lists * k or nq too large");
         DeviceGuard g(device);
-        const uint32_t threads = std::max<uint32_t>(lists * k, k);
-        hipLaunchKernelGGL(knn_merge_lists_kernel, dim3((threads + 255) / 256, nq), dim3(256), 0, (hipStream_t)stream, d_idx_in,
-                           d_dist_in, lists, k, (size_t)nq * k, d_idx, d_dist);
-        HIP_CHECK(hipGetLastError());
+        knn_merge_lists_device(d_idx_in, d_dist_in, lists, nq, k, d_idx, d_dist, (hipStream_t)stream);
     });
 }
 

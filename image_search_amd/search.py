@@ -156,11 +156,18 @@ class Pipeline:
     (mi_pipeline_*): `ingest` uploads, embeds and inserts a chunk without a readback; `query`
     scans on a second stream under the next chunk's forward; `sync` delivers the results."""
 
-    def __init__(self, model, table: "EmbeddingTable"):
+    def __init__(self, model, table):
+        """model: one image tower and table: an EmbeddingTable on its GPU — or, for ONE process over several GPUs
+        (mi_pipeline_create_sharded), a list of towers, models[s] on the device of shard s of a ShardedTable."""
         self._h = c_vp()
         self.model, self.table = model, table  # borrowed: keep them alive
         self._pending = []
-        check(lib().mi_pipeline_create(model._h, table._h, ctypes.byref(self._h)))
+        if isinstance(table, ShardedTable):
+            models = list(model) if isinstance(model, (list, tuple)) else [model] * table.info()["shards"]
+            arr = (c_vp * len(models))(*[m._h for m in models])
+            check(lib().mi_pipeline_create_sharded(arr, len(models), table._h, ctypes.byref(self._h)))
+        else:
+            check(lib().mi_pipeline_create(model._h, table._h, ctypes.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -234,7 +241,7 @@ class ShardedTable:
     reference's one-handle, one-search-at-a-time shape (main.rs:30-35, search.rs:26) for BASELINE config 5.
     Same `insert` / `knn` surface as EmbeddingTable; ids are global insertion ordinals."""
 
-    TRANSPORTS = {0: "single shard", 1: "host gather", 2: "rccl all-gather"}
+    TRANSPORTS = {0: "single shard", 1: "device copies", 2: "rccl all-gather"}
 
     def __init__(self, dim: int = 768, devices: Sequence[int] = (0,), block_rows: int = 0):
         self._h = c_vp()
@@ -272,10 +279,39 @@ class ShardedTable:
     def insert_synthetic(self, seed: int, first_row: int, n: int):
         check(lib().mi_knn_sharded_append_synthetic(self._h, seed, first_row, n))
 
+    def insert_device(self, d_ptr: int, n: int, src_device: int = 0, stream: int = 0) -> int:
+        """rows already in device memory on `src_device`: routed to their shards device to device (mi_knn_sharded_append_device)"""
+        first = ctypes.c_uint64()
+        check(lib().mi_knn_sharded_append_device(self._h, d_ptr, n, src_device, stream, ctypes.byref(first)))
+        return first.value
+
+    def shard_rows(self, s: int) -> int:
+        h = lib().mi_knn_sharded_shard(self._h, s)
+        n = ctypes.c_uint64()
+        check(lib().mi_knn_size(c_vp(h), ctypes.byref(n)))
+        return n.value
+
     def rows(self, first: int, n: int) -> np.ndarray:
         out = np.empty((n, self.dim), np.float32)
         check(lib().mi_knn_sharded_get_rows(self._h, first, n, out.ctypes.data))
         return out
+
+    def knn_async(self, reference: np.ndarray, k: int = K_REFERENCE):
+        """mi_knn_sharded_search_async: returns (ids, distances) arrays that are filled by sync()."""
+        q = _f32(reference).reshape(-1, self.dim)
+        idx = np.full((q.shape[0], k), NO_ID, np.uint64)
+        dist = np.full((q.shape[0], k), np.inf, np.float32)
+        check(lib().mi_knn_sharded_search_async(self._h, q.ctypes.data, q.shape[0], k, idx.ctypes.data, dist.ctypes.data))
+        self._pending = getattr(self, "_pending", []) + [(idx, dist)]
+        return idx, dist
+
+    def sync(self):
+        check(lib().mi_knn_sharded_sync(self._h))
+        self._pending = []
+
+    def rebalance_from(self, src: "ShardedTable"):
+        """every row of `src` into this empty table, device to device (mi_knn_sharded_rebalance)"""
+        check(lib().mi_knn_sharded_rebalance(self._h, src._h))
 
     def knn(self, reference: np.ndarray, k: int = K_REFERENCE):
         q = _f32(reference)

@@ -230,23 +230,43 @@ int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint3
  *           dealt round-robin to the shards (block_rows = 0 -> 4096; a multiple of 64).  Appends keep ids global.
  *   search  the query goes to every device, the shards scan concurrently on their own streams, the per-shard
  *           top-k lists (12 k bytes per shard and query) are all-gathered — RCCL ncclAllGather over xGMI between
- *           distinct devices; through pinned host memory when a device is listed twice or librccl is absent —
- *           and merged once.  Result = what ONE mi_knn holding every row returns, bit for bit.
+ *           distinct devices; device-to-device / peer copies into the first shard's buffer when a device is listed twice
+ *           or librccl is absent — and merged once, on the device.  Result = what ONE mi_knn holding every row returns,
+ *           bit for bit.
  * A device may be listed more than once (several shards on one GPU: how a one-GPU box tests n > 1). */
 int mi_knn_sharded_create(uint32_t dim, const int* devices, int n_dev, uint32_t block_rows, mi_knn_sharded** out);
 void mi_knn_sharded_free(mi_knn_sharded* t);
-/* any of the outputs may be NULL; transport: 0 = single shard, 1 = host gather, 2 = RCCL all-gather */
+/* any of the outputs may be NULL; transport: 0 = single shard, 1 = device-to-device / peer copies, 2 = RCCL all-gather */
 int mi_knn_sharded_info(const mi_knn_sharded* t, uint64_t* rows, uint32_t* n_shards, uint32_t* block_rows, int* transport);
 int mi_knn_sharded_set_option(mi_knn_sharded* t, const char* key, int value); /* mi_knn_set_option on every shard */
 int mi_knn_sharded_reserve(mi_knn_sharded* t, uint64_t rows);
 int mi_knn_sharded_append(mi_knn_sharded* t, const float* rows, uint64_t n, uint64_t* first_id /* may be NULL */);
+/* Rows that are already in device memory, on ANY device of the process (src_device; e.g. straight from
+ * mi_clip_embed_device of a replica there): every run goes to its shard by a device-to-device copy (same GPU) or
+ * hipMemcpyPeerAsync over xGMI (another GPU), enqueued on `stream` — a stream of src_device, NULL = its null stream — with
+ * no trip through the host and no host block; searches enqueued afterwards see the rows.  A failure leaves the table as it was. */
+int mi_knn_sharded_append_device(mi_knn_sharded* t, const float* d_rows, uint64_t n, int src_device, void* stream,
+                                 uint64_t* first_id /* may be NULL */);
 int mi_knn_sharded_append_synthetic(mi_knn_sharded* t, uint64_t seed, uint64_t first_row, uint64_t n);
+/* shard s of the table, borrowed (its device, its size, mi_knn_get_rows on local rows, ...); NULL when out of range */
+mi_knn* mi_knn_sharded_shard(mi_knn_sharded* t, uint32_t s);
 int mi_knn_sharded_get_rows(mi_knn_sharded* t, uint64_t first, uint64_t n, float* out);
 int mi_knn_sharded_search(mi_knn_sharded* t, const float* q, uint32_t nq, uint32_t k, uint64_t* idx, float* dist);
-/* `<prefix>.<s>of<n>.miknn` per shard + `<prefix>.shards`; load needs an empty table and re-deals the blocks when the
- * shard count or block size differ from the saved ones (rebalancing through the host). */
+/* The same search without the wait: everything (query upload, the shards' scans, exchange, merge, readback) is enqueued
+ * and the call returns; idx / dist (caller-owned, must stay valid) are filled when mi_knn_sharded_sync returns, or when 8
+ * later searches have been enqueued.  q is copied before the call returns. */
+int mi_knn_sharded_search_async(mi_knn_sharded* t, const float* q, uint32_t nq, uint32_t k, uint64_t* idx, float* dist);
+int mi_knn_sharded_sync(mi_knn_sharded* t);
+/* `<prefix>.g<gen>.<s>of<n>.miknn` per shard + the manifest `<prefix>.shards` (n, block, rows, dim, gen), written last:
+ * every save is a new GENERATION of files, the previous one is deleted only after the manifest names the new one, so a
+ * crash or an I/O error at any point of a save leaves a complete, loadable table on disk.  load needs an empty table
+ * (and leaves it empty on failure) and re-deals the blocks when the shard count or block size differ from the saved ones. */
 int mi_knn_sharded_save(mi_knn_sharded* t, const char* prefix);
 int mi_knn_sharded_load(mi_knn_sharded* t, const char* prefix);
+/* Change the layout of a LIVE table: every row of `src` into the empty `dst` (another shard count, device set or block
+ * size), block by block, device to device — a plain copy where source and destination shard share a GPU,
+ * hipMemcpyPeerAsync over xGMI where they do not; nothing passes through the host.  src is unchanged. */
+int mi_knn_sharded_rebalance(mi_knn_sharded* dst, mi_knn_sharded* src);
 /* the placement arithmetic by itself (host-only): global row <-> (shard, local row) */
 int mi_knn_sharded_place(uint32_t block_rows, uint32_t n_shards, uint64_t row, uint32_t* shard, uint64_t* local);
 int mi_knn_sharded_id(uint32_t block_rows, uint32_t n_shards, uint32_t shard, uint64_t local, uint64_t* row);
@@ -279,6 +299,17 @@ int mi_knn_merge_device(int device, const uint64_t* d_idx_in, const float* d_dis
  * width.  Both are borrowed and must outlive the pipeline; they stay usable through their own
  * entry points (the handles order all work, see Conventions). */
 int mi_pipeline_create(mi_clip* model, mi_knn* table, mi_pipeline** out);
+/* The same pipeline for ONE process over several GPUs (BASELINE config 5 as the reference's single server would run it:
+ * one AppState, scan task and search handler side by side, server/src/main.rs:30-35): models[s] is the tower replica on the
+ * device of the table's shard s (n_models == shard count; one handle may serve several shards of its GPU).
+ *   ingest  a chunk is cut at the table's block boundaries; every run is uploaded to, and embedded by, the replica on the
+ *           GPU that owns its block, whose last kernel writes the rows straight into that shard ("each
+ *           replica appends its embeddings to its local shard"); runs of consecutive blocks occupy different GPUs at once,
+ *           so a table created with block_rows = the chunk size per GPU keeps every replica busy.
+ *   query   mi_knn_sharded_search_async: the shards scan side by side, lists all-gathered and merged on the device.
+ * mi_pipeline_ingest / query / sync / drain / stats / free serve both forms (drain delivers everything pending here;
+ * mi_pipeline_query_device is for the one-GPU form, whose caller does the exchange). */
+int mi_pipeline_create_sharded(mi_clip* const* models, int n_models, mi_knn_sharded* table, mi_pipeline** out);
 void mi_pipeline_free(mi_pipeline* p);
 /* Enqueue one chunk: nchw = [n,3,H,W] f32, host memory.  The n embeddings become rows
  * [size, size+n) of the table; *first_id (may be NULL) = id of the first one.  Returns when the
@@ -294,8 +325,9 @@ int mi_pipeline_ingest(mi_pipeline* p, const float* nchw, size_t n, uint64_t* fi
 int mi_pipeline_query(mi_pipeline* p, const float* q, uint32_t k, uint64_t* idx, float* dist);
 /* As mi_pipeline_query, the k results left on the device (d_idx [k] uint64, d_dist [k] f32, caller-owned, same device):
  * the per-shard list of a row-sharded table, ready for the all-gather without a trip through the host.  The scan runs
- * on the pipeline's search stream; `consumer_stream` (a hipStream_t, may be NULL) is made to wait for it — an event, no
- * host block — so work enqueued on that stream afterwards (the collective) sees the results. */
+ * on the pipeline's search stream; `consumer_stream` (a hipStream_t; NULL = the device's default stream, e.g. what
+ * torch.cuda.current_stream() is unless the caller changed it) is made to wait for it — an event, no host block — so work
+ * enqueued on that stream afterwards (the collective) sees the results. */
 int mi_pipeline_query_device(mi_pipeline* p, const float* q, uint32_t k, uint64_t* d_idx, float* d_dist, void* consumer_stream);
 /* Wait for everything enqueued and deliver the pending query results. */
 int mi_pipeline_sync(mi_pipeline* p);

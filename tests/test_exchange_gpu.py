@@ -102,3 +102,52 @@ def test_pipeline_query_device_leaves_the_host_results_on_the_device(built, tmp_
     pipe.close()
     t.close()
     m.close()
+
+
+def test_shard_exchange_over_rccl_one_rank(built, tmp_path):
+    """The nccl (= RCCL) form of ShardExchange end to end with the one rank a one-GPU box allows: scan -> packed device
+    list -> all_gather_into_tensor -> pinned readback -> merge, several exchanges in flight; the merged list of one
+    shard is that shard's own list.  (Two ranks on one GPU are refused by RCCL; bench.py rehearses those over gloo.)"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from image_search_amd.search import ShardExchange
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg = synth.VitConfig.tiny()
+        path = str(tmp_path / "tiny.safetensors")
+        synth.save_safetensors(synth.vit_weights(cfg, 1), path, {"num_attention_heads": cfg.heads})
+        m = Model.from_file(path, 0, PRECISION_F32)
+        t = EmbeddingTable(64, 0)
+        t.reserve(400_000)
+        t.insert_synthetic(3, 0, 300_000)
+        pipe = Pipeline(m, t)
+        px = synth.preprocess_rgb8(synth.images_u8(3, 40, cfg.image))
+        qs = synth.corpus_rows(4, 0, 12, 64)
+        for k in (10, 1000):
+            ex = ShardExchange(k, depth=4)
+            assert ex.on_device and ex.world == 1
+            want, got = [], []
+            for u in range(12):
+                if u % 4 == 0:
+                    pipe.ingest(px)
+                want.append(pipe.query(qs[u], k))
+                ex.query(pipe, qs[u])
+                while ex.in_flight() > 3:
+                    got.append(ex.collect())
+            pipe.sync()
+            while ex.in_flight():
+                got.append(ex.collect())
+            assert len(got) == 12
+            for (wi, wd), (gi, gd) in zip(want, got):
+                assert np.array_equal(wi, gi) and np.array_equal(wd.view(np.uint32), gd.view(np.uint32))
+            ex.submit(*want[0])                       # the host-list form over the same backend
+            gi, gd = ex.collect()
+            assert np.array_equal(want[0][0], gi) and np.array_equal(want[0][1].view(np.uint32), gd.view(np.uint32))
+        pipe.close()
+        t.close()
+        m.close()
+    finally:
+        dist.destroy_process_group()

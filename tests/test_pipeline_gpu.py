@@ -239,3 +239,53 @@ def test_bf16_retrieval_agrees_with_fp32_and_outlier_channels_do_not_matter(buil
     err16, _ = report["outliers, function changed"]["bf16"]
     errsp, agree_sp = report["outliers, function changed"]["bf16_split"]
     assert err16 <= 6e-2 and errsp <= err16 * 1.05 and agree_sp[10] >= 0.97, report["outliers, function changed"]
+
+
+def test_sharded_pipeline_one_process_replicas_feed_their_own_shards(built, tmp_path, orc):
+    """mi_pipeline_create_sharded (BASELINE config 5 as the reference's ONE server process would run it,
+    server/src/main.rs:30-35 + server/src/clip.rs:112-137): a tower replica per shard, every run of a chunk embedded on
+    the GPU that owns its block and written straight into that shard, queries over all shards with the device-side
+    exchange.  One GPU here, so the three shards (and replicas) share device 0; rows, ids and results must be those of
+    the one-GPU pipeline over one table, and of the oracle."""
+    from image_search_amd.search import ShardedTable
+    cfg = synth.VitConfig.tiny()
+    path = str(tmp_path / "tiny.safetensors")
+    synth.save_safetensors(synth.vit_weights(cfg, 1), path, {"num_attention_heads": cfg.heads})
+    models = [Model.from_file(path, 0, PRECISION_F32) for _ in range(2)]
+    px = synth.preprocess_rgb8(synth.images_u8(21, 300, cfg.image))
+    want_rows = models[0].forward(px)
+
+    base = synth.corpus_rows(23, 0, 1000, 64)
+    st = ShardedTable(64, [0, 0, 0], 64)                       # blocks of 64 rows: a 300-image chunk spans all replicas
+    st.insert(base)
+    pipe = Pipeline([models[0], models[1], models[0]], st)    # a replica may serve several shards of its GPU
+    one = EmbeddingTable(64, 0)
+    one.insert(base)
+    ref = Pipeline(models[1], one)
+
+    qs = synth.corpus_rows(24, 0, 4, 64)
+    got, want = [], []
+    for p_, out in ((pipe, got), (ref, want)):
+        out.append(p_.query(qs[0], 10))                        # before any ingest: the base rows only
+        assert p_.ingest(px[:100]) == 1000
+        out.append(p_.query(qs[1], 10))
+        assert p_.ingest(px[100:101]) == 1100                  # a single image, mid-block
+        assert p_.ingest(px[101:]) == 1101                     # 199 images: crosses three block boundaries
+        out.append(p_.query(want_rows[150], 5))                # an ingested row itself: distance ~0 at its own id
+        out.append(p_.query(qs[2], 1000))
+        assert p_.ingest(px[:0]) == 1300                       # n = 0 (clip.rs:112-118)
+        p_.sync()
+    assert len(st) == 1300 and sum(st.shard_rows(s) for s in range(3)) == 1300
+    assert np.array_equal(st.rows(1000, 300).view(np.uint32), want_rows.view(np.uint32))    # same kernels, same bits, in order
+    all_rows = np.concatenate([base, want_rows])
+    for (gi, gd), (wi, wd) in zip(got, want):
+        gi, gd = gi.reshape(-1), gd.reshape(-1)
+        assert np.array_equal(gi, wi) and np.array_equal(gd.view(np.uint32), wd.view(np.uint32))
+    assert int(got[2][0].reshape(-1)[0]) == 1150
+    oi, od = orc_knn(orc, qs[2], all_rows, 1000)
+    assert np.array_equal(got[3][0].reshape(-1), oi) and np.array_equal(got[3][1].reshape(-1).view(np.uint32), od.view(np.uint32))
+    n_f, ms_f, _, _ = pipe.stats()
+    assert n_f >= 6 and ms_f > 0                               # forwards of every lane are timed
+    pipe.close(); ref.close(); st.close(); one.close()
+    for m in models:
+        m.close()

@@ -1,7 +1,7 @@
 """mi_knn_sharded on a real MI355X through the C ABI: the table row-sharded inside ONE process
 (BASELINE config 5 in miniature; the reference's one-handle shape, server/src/main.rs:30-35).
 
-A one-GPU box has one device: n > 1 shards are put on device 0 several times (host gather transport);
+A one-GPU box has one device: n > 1 shards are put on device 0 several times (the lists meet by device-to-device copies);
 the RCCL transport is exercised with its one-rank communicator.  On an 8-GPU node the same entry points
 take distinct devices and the all-gather runs over xGMI — unmeasured on hardware so far.
 Everything is compared bit for bit with ONE mi_knn holding every row and with the oracle."""
@@ -49,7 +49,7 @@ def test_shards_on_one_gpu_equal_the_single_table_and_the_oracle(built, orc, n_s
     assert sh.insert(rows[:10_000]) == 0
     assert sh.insert(rows[10_000:10_001]) == 10_000   # appends of any size keep ids global and shards contiguous
     assert sh.insert(rows[10_001:]) == 10_001
-    assert sh.info() == {"rows": n, "shards": n_shards, "block_rows": block, "transport": "host gather"}
+    assert sh.info() == {"rows": n, "shards": n_shards, "block_rows": block, "transport": "device copies"}
     assert np.array_equal(sh.rows(0, n), rows)
     qs = np.concatenate([synth.corpus_rows(42, 0, 3), rows[7:8]])
     for k in (10, 1000):
@@ -84,11 +84,104 @@ def test_save_load_and_rebalancing_to_another_shard_count(built, tmp_path):
         with pytest.raises(MiError):
             b.load(prefix)                                                   # needs an empty table
         b.close()
-    os.remove(prefix + ".1of3.miknn")
+    os.remove(prefix + ".g1.1of3.miknn")
     c = ShardedTable(768, [0, 0], 256)
     with pytest.raises(MiError):
         c.load(prefix)
+    assert len(c) == 0 and [c.shard_rows(s) for s in range(2)] == [0, 0]    # a failed load leaves the table empty ...
+    c.insert(rows[:700])                                                     # ... and usable
+    assert np.array_equal(c.rows(0, 700), rows[:700])
     c.close(); same.close(); a.close()
+
+
+def test_a_save_that_fails_midway_leaves_the_previous_generation_loadable(built, tmp_path, monkeypatch):
+    """shard files used to be replaced one by one under the same names, so an error after the first rename left
+    mixed generations that no longer loaded.  Every save now writes a new generation and the manifest names it last."""
+    n = 9_000
+    rows = synth.corpus_rows(53, 0, n)
+    a = ShardedTable(768, [0, 0, 0], 256)
+    a.insert(rows[:6_000])
+    prefix = str(tmp_path / "t")
+    a.save(prefix)                                                           # generation 1
+    a.insert(rows[6_000:])
+    monkeypatch.setenv("MI_KNN_SHARDED_SAVE_FAIL_AFTER", "2")                # the third shard file cannot be written
+    with pytest.raises(MiError):
+        a.save(prefix)
+    monkeypatch.delenv("MI_KNN_SHARDED_SAVE_FAIL_AFTER")
+    assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".miknn")) == [f"t.g1.{s}of3.miknn" for s in range(3)]
+    b = ShardedTable(768, [0, 0, 0], 256)
+    b.load(prefix)                                                           # what the crash left: generation 1, complete
+    assert len(b) == 6_000 and np.array_equal(b.rows(0, 6_000), rows[:6_000])
+    b.close()
+    a.save(prefix)                                                           # generation 2; generation 1 is deleted after the manifest
+    assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".miknn")) == [f"t.g2.{s}of3.miknn" for s in range(3)]
+    c = ShardedTable(768, [0, 0], 1024)
+    c.load(prefix)
+    assert len(c) == n and np.array_equal(c.rows(0, n), rows)
+    c.close(); a.close()
+
+
+def test_rows_born_on_the_device_reach_their_shards_without_the_host(built, orc):
+    """mi_knn_sharded_append_device: runs of a device buffer routed to their shards (here: device-to-device; between GPUs:
+    hipMemcpyPeerAsync), on the producer's stream, searches ordered behind them by events only."""
+    import torch
+    n = 30_000 + 5
+    rows = synth.corpus_rows(71, 0, n)
+    one = EmbeddingTable(768, 0)
+    one.insert(rows)
+    sh = ShardedTable(768, [0, 0, 0], 192)
+    producer = torch.cuda.Stream()
+    with torch.cuda.stream(producer):
+        d = torch.from_numpy(rows).cuda(non_blocking=True)                  # "produced" on the stream the append is given
+    assert sh.insert(rows[:1_000]) == 0                                      # host and device appends interleave
+    assert sh.insert_device(d[1_000:].data_ptr(), 10_000, 0, producer.cuda_stream) == 1_000
+    assert sh.insert_device(d[11_000:].data_ptr(), 1, 0, producer.cuda_stream) == 11_000
+    assert sh.insert_device(d[11_001:].data_ptr(), n - 11_001, 0, producer.cuda_stream) == 11_001
+    qs = synth.corpus_rows(72, 0, 3)
+    got = sh.knn(qs, 10)                                                     # no synchronisation in between
+    assert _same(got, one.knn(qs, 10))
+    for u in range(3):
+        oi, od = orc_knn(orc, qs[u], rows, 10)
+        assert np.array_equal(got[0][u], oi) and np.array_equal(got[1][u].view(np.uint32), od.view(np.uint32))
+    assert np.array_equal(sh.rows(0, n), rows)
+    assert sum(sh.shard_rows(s) for s in range(3)) == n
+    sh.close(); one.close()
+
+
+def test_async_searches_in_flight_and_the_ring(built):
+    n = 40_000
+    sh = ShardedTable(768, [0, 0, 0, 0], 512)
+    sh.insert_synthetic(81, 0, n)
+    one = EmbeddingTable(768, 0)
+    one.insert_synthetic(81, 0, n)
+    qs = synth.corpus_rows(82, 0, 20)
+    pend = [sh.knn_async(qs[u], 10 if u % 3 else 1000) for u in range(20)]   # more than the 8 slots: the oldest are delivered on the way
+    sh.sync()
+    for u, (gi, gd) in enumerate(pend):
+        assert _same((gi[0], gd[0]), one.knn(qs[u], 10 if u % 3 else 1000))
+    gi, gd = sh.knn_async(qs[:5], 64)                                        # several queries per call
+    sh.sync()
+    assert _same((gi, gd), one.knn(qs[:5], 64))
+    sh.close(); one.close()
+
+
+def test_a_live_table_changes_its_layout_device_to_device(built):
+    """mi_knn_sharded_rebalance: the f3 remainder — a shard-count change of a live table without a trip through the host."""
+    n = 25_000 + 33
+    rows = synth.corpus_rows(91, 0, n)
+    a = ShardedTable(768, [0, 0, 0], 256)
+    a.insert(rows)
+    q = synth.corpus_rows(92, 0, 2)
+    want = a.knn(q, 100)
+    for devices, block in (([0, 0], 1024), ([0] * 5, 64), ([0], 0)):
+        b = ShardedTable(768, devices, block)
+        b.rebalance_from(a)
+        assert len(b) == n and np.array_equal(b.rows(0, n), rows) and _same(b.knn(q, 100), want)
+        with pytest.raises(MiError):
+            b.rebalance_from(a)                                              # needs an empty destination
+        b.close()
+    assert len(a) == n and _same(a.knn(q, 100), want)                        # the source is unchanged
+    a.close()
 
 
 def test_rccl_transport_with_its_one_rank_communicator(built, monkeypatch):
