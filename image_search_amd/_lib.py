@@ -42,6 +42,7 @@ SYMBOLS = {
     "mi_knn_set_base": (ctypes.c_int, [c_vp, ctypes.c_uint64]),
     "mi_knn_set_option": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
     "mi_knn_prefilter_stats": (ctypes.c_int, [c_vp, c_vp, c_vp]),
+    "mi_knn_prefilter_state": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "mi_knn_reserve": (ctypes.c_int, [c_vp, ctypes.c_uint64]),
     "mi_knn_size": (ctypes.c_int, [c_vp, c_u64p]),
     "mi_knn_append": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint64]),

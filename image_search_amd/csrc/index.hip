@@ -260,6 +260,8 @@ int mi_index_save(mi_index* ix, const char* dir) {
         }
         if (::close(fd) != 0) fail(MI_ERR_IO, "close of %s failed", tmp.c_str());
         if (std::rename(tmp.c_str(), fin.c_str()) != 0) fail(MI_ERR_IO, "cannot rename %s", tmp.c_str());
+        const int dfd = ::open(dir, O_RDONLY);  // the renames themselves become durable with the directory
+        if (dfd >= 0) { (void)::fsync(dfd); ::close(dfd); }
     });
 }
 
@@ -267,10 +269,16 @@ int mi_index_load(mi_index* ix, const char* dir) {
     return guarded([&] {
         if (!ix || !dir) fail(MI_ERR_INVALID, "null argument");
         std::lock_guard<std::mutex> l(ix->mu);
-        if (!ix->paths.empty()) fail(MI_ERR_INVALID, "mi_index_load needs an empty index");
+        uint64_t have = 0;
+        (void)mi_knn_size(ix->table, &have);
+        // (rows the pipeline has written into the table but mi_index_adopt has not named yet count too)
+        if (!ix->paths.empty() || have != 0) fail(MI_ERR_INVALID, "mi_index_load needs an empty index (%zu paths, %llu embeddings)",
+                                                  ix->paths.size(), (unsigned long long)have);
         const std::string d(dir), pf = d + "/image_path.bin";
         FILE* f = std::fopen(pf.c_str(), "rb");
         if (!f) fail(MI_ERR_IO, "cannot open %s", pf.c_str());
+        struct stat sb {};
+        const uint64_t file_bytes = ::fstat(fileno(f), &sb) == 0 ? (uint64_t)sb.st_size : 0;
         std::vector<std::string> paths;
         std::string media;
         try {
@@ -285,6 +293,9 @@ int mi_index_load(mi_index* ix, const char* dir) {
                 if (n && std::fread(&(*s)[0], 1, n, f) != n) fail(MI_ERR_IO, "%s is truncated", pf.c_str());
             };
             get(&media);
+            // every row costs at least its 4-byte length: a count the file cannot hold is corruption, not an allocation request
+            if (rows > file_bytes / 4) fail(MI_ERR_IO, "%s claims %llu rows in %llu bytes", pf.c_str(), (unsigned long long)rows,
+                                            (unsigned long long)file_bytes);
             paths.resize(rows);
             for (auto& p : paths) get(&p);
         } catch (...) {
@@ -299,10 +310,7 @@ int mi_index_load(mi_index* ix, const char* dir) {
         // the embedding file is written first: it may be NEWER than the path file (a crash between the two renames);
         // rows without a path cannot be served and are not kept.  The other way round cannot happen.
         if (rows < paths.size()) fail(MI_ERR_IO, "%s: %llu embeddings for %zu paths", dir, (unsigned long long)rows, paths.size());
-        if (rows > paths.size()) {
-            ix->table->rows = paths.size();
-            ix->table->mirror_rows = std::min<uint64_t>(ix->table->mirror_rows, paths.size());  // (rows beyond are rewritten by later inserts)
-        }
+        if (rows > paths.size()) knn_truncate(ix->table, paths.size());  // under the table's own lock; rows beyond are rewritten by later inserts
         ix->media_dir = media;
         for (const auto& p : paths) add_path(ix, p);
     });

@@ -32,6 +32,18 @@ void ensure(mi_knn* t, void** p, size_t* have, size_t want, size_t elem) {
     *have = want;
 }
 
+// as ensure(), keeping the first `keep` elements (a mirror that grows with the table must not be rebuilt from the fp32 rows)
+void ensure_keep(mi_knn* t, void** p, size_t* have, size_t want, size_t elem, size_t keep) {
+    if (*have >= want) return;
+    t->reads.sync();
+    void* np_ = nullptr;
+    HIP_CHECK(hipMalloc(&np_, want * elem));
+    if (*p && keep) HIP_CHECK(hipMemcpy(np_, *p, std::min(keep, *have) * elem, hipMemcpyDeviceToDevice));
+    if (*p) HIP_CHECK(hipFree(*p));
+    *p = np_;
+    *have = want;
+}
+
 // the handle's own stream, created on first use (an idle stream still takes one of the four
 // hardware queues HIP multiplexes streams onto)
 hipStream_t own_stream(mi_knn* t) {
@@ -151,24 +163,27 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s)
     ensure(t, (void**)&t->d_pref_flag, &t->pref_flag_cap, (size_t)4, sizeof(uint32_t));
     const bool bytes = t->prefilter == 2;
     const size_t mirror_elems = bytes ? ((size_t)t->cap * t->dim + 1) / 2 : (size_t)t->cap * t->dim;  // in uint16 units
-    if (t->mirror_cap < mirror_elems || t->xx_cap < (size_t)t->cap || (bytes && t->scale8_cap < (size_t)t->cap)) t->mirror_rows = 0;  // (re)allocated below: rebuild
     t->mirror_rows = std::min(t->mirror_rows, t->rows);
-    ensure(t, (void**)&t->d_mirror, &t->mirror_cap, mirror_elems, sizeof(uint16_t));
-    ensure(t, (void**)&t->d_xx, &t->xx_cap, (size_t)t->cap, sizeof(float));
+    if (bytes && t->g8_ready && t->rows >= 4 * std::max<uint64_t>(t->g8_rows, 1)) t->g8_ready = false;  // the table has grown 4x since the
+                                                                                    // channel scales were taken: look again
+    if (bytes && !t->g8_ready) t->mirror_rows = 0;  // new scales: every byte row changes
+    // the table grew past the mirror's allocation: the rows mirrored so far move over, only the new ones are converted
+    const size_t keep_m = bytes ? ((size_t)t->mirror_rows * t->dim + 1) / 2 : (size_t)t->mirror_rows * t->dim;
+    ensure_keep(t, (void**)&t->d_mirror, &t->mirror_cap, mirror_elems, sizeof(uint16_t), keep_m);
+    ensure_keep(t, (void**)&t->d_xx, &t->xx_cap, (size_t)t->cap, sizeof(float), (size_t)t->mirror_rows);
     if (bytes) {
-        ensure(t, (void**)&t->d_scale8, &t->scale8_cap, (size_t)t->cap, sizeof(float));
-        ensure(t, (void**)&t->d_cfac8, &t->cfac8_cap, (size_t)t->cap, sizeof(float));
+        ensure_keep(t, (void**)&t->d_scale8, &t->scale8_cap, (size_t)t->cap, sizeof(float), (size_t)t->mirror_rows);
+        ensure_keep(t, (void**)&t->d_cfac8, &t->cfac8_cap, (size_t)t->cap, sizeof(float), (size_t)t->mirror_rows);
         ensure(t, (void**)&t->d_rho8, &t->rho8_cap, (size_t)4, sizeof(float));
         ensure(t, (void**)&t->d_g8, &t->g8_cap, (size_t)2 * t->dim, sizeof(float));
-        if (t->mirror_rows == 0) t->g8_ready = false;  // a rebuild may as well look at the rows again
-        if (!t->g8_ready) {  // the channel scales: RMS per dimension over the first rows (any positive values are correct)
-            const uint64_t sample = std::min<uint64_t>(t->rows, 1u << 16);
+        if (!t->g8_ready) {  // the channel scales: RMS per dimension over a sample spread over the table (any positive values are correct)
+            const uint64_t sample = std::min<uint64_t>(t->rows, 1u << 16), stride = t->rows / sample;
             HIP_CHECK(hipMemsetAsync(t->d_g8 + t->dim, 0, t->dim * sizeof(float), s));
-            hipLaunchKernelGGL(knn_channel_sumsq_kernel, dim3(256), dim3(256), 0, s, t->table, sample, (int)t->dim, t->d_g8 + t->dim);
+            hipLaunchKernelGGL(knn_channel_sumsq_kernel, dim3(256), dim3(256), 0, s, t->table, sample, stride, (int)t->dim, t->d_g8 + t->dim);
             hipLaunchKernelGGL(knn_channel_scale_kernel, dim3((t->dim + 255) / 256), dim3(256), 0, s, t->d_g8 + t->dim, sample,
                                (int)t->dim, t->d_g8);
             t->g8_ready = true;
-            t->mirror_rows = 0;
+            t->g8_rows = t->rows;
         }
     }
     const uint64_t n_tiles = (t->rows + 63) / 64;
@@ -276,6 +291,59 @@ void select_pass(mi_knn* t, const float* d_q, uint32_t k, uint64_t* keys_out, hi
     HIP_CHECK(hipGetLastError());
 }
 
+// ---- feedback of the two-stage search (handles.h: pref_*) -------------------------------------------------------
+void pref_fold(mi_knn* t, uint32_t cand, uint32_t fell_back) {
+    t->pref_consec = fell_back ? t->pref_consec + 1 : 0;
+    t->pref_hist[t->pref_hist_n++ % mi_knn::PREF_RING] = cand;
+    bool skip = t->pref_consec >= 2;
+    if (!skip && t->pref_hist_n >= 4) {  // the median of the last counts: a corpus that keeps stage 2 busy with > 2^20 rows per query
+        uint32_t v[mi_knn::PREF_RING];
+        const uint32_t m = std::min<uint32_t>(t->pref_hist_n, mi_knn::PREF_RING);
+        std::copy(t->pref_hist, t->pref_hist + m, v);
+        std::nth_element(v, v + m / 2, v + m);
+        skip = v[m / 2] > (1u << 20);
+    }
+    if (skip) {
+        t->pref_skip_left = mi_knn::PREF_SKIP;
+        t->pref_consec = 0;
+        t->pref_hist_n = 0;
+    }
+}
+// fold what has arrived, oldest first, without waiting for anything
+void pref_poll(mi_knn* t) {
+    for (uint64_t q = t->pref_seq >= (uint64_t)mi_knn::PREF_RING ? t->pref_seq - mi_knn::PREF_RING : 0; q < t->pref_seq; ++q) {
+        const int i = (int)(q % mi_knn::PREF_RING);
+        if (!t->pref_ev_pending[i]) continue;
+        if (hipEventQuery(t->pref_ev[i]) != hipSuccess) { (void)hipGetLastError(); break; }  // keep the order: stop at the first one still in flight
+        t->pref_ev_pending[i] = false;
+        pref_fold(t, t->h_pref_ring[2 * i], t->h_pref_ring[2 * i + 1]);
+    }
+}
+// behind a two-stage search on `s`: {candidates, fell back} -> pinned memory, an event to say when
+void pref_record(mi_knn* t, hipStream_t s) {
+    if (!t->h_pref_ring) HIP_CHECK(hipHostMalloc((void**)&t->h_pref_ring, (size_t)mi_knn::PREF_RING * 2 * sizeof(uint32_t), hipHostMallocDefault));
+    const int i = (int)(t->pref_seq % mi_knn::PREF_RING);
+    if (t->pref_ev_pending[i]) return;  // eight readbacks still in flight: this query goes unreported rather than waited for
+    if (!t->pref_ev[i]) HIP_CHECK(hipEventCreateWithFlags(&t->pref_ev[i], hipEventDisableTiming));
+    HIP_CHECK(hipMemcpyAsync(t->h_pref_ring + 2 * i, t->d_pref_flag, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipEventRecord(t->pref_ev[i], s));
+    t->pref_ev_pending[i] = true;
+    ++t->pref_seq;
+}
+void pref_reset(mi_knn* t) {
+    for (int i = 0; i < mi_knn::PREF_RING; ++i) {
+        if (t->pref_ev_pending[i]) (void)hipEventSynchronize(t->pref_ev[i]);
+        t->pref_ev_pending[i] = false;
+    }
+    t->pref_hist_n = t->pref_consec = t->pref_skip_left = 0;
+}
+
+// lists a register-path pass writes (the grid of one_pass<WaveTopReg>)
+uint32_t reg_pass_lists(const mi_knn* t) {
+    const uint64_t n_tiles = (t->rows + 63) / 64;
+    return 4 * std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 4, (n_tiles + 3) / 4));
+}
+
 void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
     if (t->rows == 0) {  // nothing stored: k "none" entries
         hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s,
@@ -286,7 +354,22 @@ void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float*
     const uint32_t passes = (k + 1023) / 1024;
     ensure(t, (void**)&t->d_keys, &t->keys_cap, (size_t)std::max<uint32_t>(passes * 1024, 4096), sizeof(uint64_t));
     t->last_prefiltered = prefilter_applies(t, k);
+    if (t->last_prefiltered && t->pref_adaptive) {
+        pref_poll(t);
+        if (t->pref_skip_left) {  // this corpus has been defeating the mirror: the single pass alone, for a while
+            --t->pref_skip_left;
+            ++t->pref_skipped;
+            t->last_prefiltered = false;
+        }
+    }
     if (t->last_prefiltered) {
+        // every workspace of this search at its final size BEFORE the first launch: growing one later would free a buffer
+        // that kernels already queued on `s` still use (ensure() only waits for EARLIER searches)
+        if (k <= 64) {
+            const uint32_t lists = reg_pass_lists(t);
+            ensure(t, (void**)&t->d_cand, &t->cand_keys, std::max<size_t>(4096, (size_t)lists * k), sizeof(uint64_t));
+            if (lists > 64) ensure(t, (void**)&t->d_tmp, &t->tmp_keys, (size_t)((lists + 31) / 32) * k, sizeof(uint64_t));
+        }
         const uint32_t* fallback = prefilter_pass(t, d_q, k, s);
         // the single pass, every kernel of it returning at once unless *fallback
         if (k <= 64) one_pass<WaveTopReg>(t, d_q, k, nullptr, t->d_keys, s, fallback);
@@ -294,6 +377,7 @@ void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float*
         hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, id_map(t),
                            d_idx, d_dist, (size_t)0, (size_t)0, t->d_pref_keys, fallback);
         HIP_CHECK(hipGetLastError());
+        if (t->pref_adaptive) pref_record(t, s);
         return;
     }
     if (k > 64 && k <= 4096 && t->select_path) {
@@ -414,6 +498,9 @@ void mi_knn_free(mi_knn* t) {
                     (void*)t->d_xx, (void*)t->d_pref_rows, (void*)t->d_pref_keys, (void*)t->d_pref_flag, (void*)t->d_scale8,
                     (void*)t->d_cfac8, (void*)t->d_rho8, (void*)t->d_g8})
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : t->pref_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (t->h_pref_ring) (void)hipHostFree(t->h_pref_ring);
     delete t;
 }
 
@@ -435,9 +522,15 @@ int mi_knn_set_option(mi_knn* t, const char* key, int value) {
                 t->mirror_rows = 0;
                 t->g8_ready = false;
             }
+            if (value != t->prefilter) pref_reset(t);
             t->prefilter = value;
+        } else if (k == "prefilter_adaptive") {
+            // 1 (default): a corpus that makes the two-stage search fall back twice in a row (or keeps > 2^20 candidates per
+            // query) is served by the single pass alone for the next 64 queries, then probed again; 0: every query tries stage 1
+            pref_reset(t);
+            t->pref_adaptive = value != 0;
         } else {
-            fail(MI_ERR_INVALID, "unknown option '%s' (known: prefilter)", key);
+            fail(MI_ERR_INVALID, "unknown option '%s' (known: prefilter, prefilter_adaptive)", key);
         }
     });
 }
@@ -453,6 +546,20 @@ int mi_knn_prefilter_stats(mi_knn* t, uint32_t* candidates, uint32_t* fell_back)
         uint32_t w[2] = {0, 0};
         HIP_CHECK(hipMemcpy(w, t->d_pref_flag, sizeof w, hipMemcpyDeviceToHost));
         *candidates = w[0]; *fell_back = w[1];
+    });
+}
+
+int mi_knn_prefilter_state(mi_knn* t, uint32_t out[4]) {
+    return guarded([&] {
+        if (!t || !out) fail(MI_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> l(t->mu);
+        DeviceGuard g(t->device);
+        t->reads.sync();   // everything enqueued has finished, so every readback has arrived
+        pref_poll(t);
+        out[0] = t->pref_skip_left;
+        out[1] = t->pref_consec;
+        out[2] = (uint32_t)std::min<uint64_t>(t->pref_skipped, 0xFFFFFFFFull);
+        out[3] = (uint32_t)std::min<uint64_t>(t->g8_rows, 0xFFFFFFFFull);
     });
 }
 
@@ -612,6 +719,12 @@ int mi_knn_save(mi_knn* t, const char* path) {
             if (std::fclose(fp) != 0) fail(MI_ERR_IO, "close of %s failed", tmp.c_str());
         }
         if (std::rename(tmp.c_str(), path) != 0) fail(MI_ERR_IO, "cannot rename %s to %s", tmp.c_str(), path);
+        {   // the rename becomes durable with its directory
+            const std::string p(path);
+            const size_t slash = p.find_last_of('/');
+            File d((slash == std::string::npos ? std::string(".") : slash == 0 ? std::string("/") : p.substr(0, slash)).c_str(), "r");
+            if (d.f) (void)fsync(fileno(d.f));
+        }
     });
 }
 

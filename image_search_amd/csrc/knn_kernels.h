@@ -625,13 +625,14 @@ __global__ __launch_bounds__(256) void knn_prefilter_collect_kernel(const uint32
 // q.x = q'.x'.  Without it a few dimensions two orders of magnitude above the rest — what trained CLIP embeddings have —
 // set every row's scale, the bytes of all other dimensions collapse around 128 and eps_r grows to 0.2 (measured: 46 % of
 // a 1 M-row corpus became candidates); with it a = max_j |x'_j|, rho = |q'|_1 / |q|_2 and the bound is back at a few 1e-3.
-__global__ __launch_bounds__(256) void knn_channel_sumsq_kernel(const float* __restrict__ table, uint64_t n_rows, int dim,
-                                                                float* __restrict__ acc) {
-    // rows blockIdx.x, + gridDim.x, ...; thread j owns channels j, j + 256, ... (coalesced across the block)
+__global__ __launch_bounds__(256) void knn_channel_sumsq_kernel(const float* __restrict__ table, uint64_t n_rows, uint64_t row_stride,
+                                                                int dim, float* __restrict__ acc) {
+    // a sample of n_rows rows, `row_stride` apart (spread over the whole table): sample blockIdx.x, + gridDim.x, ...;
+    // thread j owns channels j, j + 256, ... (coalesced across the block)
     for (int c = threadIdx.x; c < dim; c += 256) {
         float s = 0.0f;
         for (uint64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
-            const float v = table[r * dim + c];
+            const float v = table[r * row_stride * dim + c];
             if (fabsf(v) <= 1.0e18f) s = __builtin_fmaf(v, v, s);  // (non-finite and absurd values do not get a vote)
         }
         atomicAdd(&acc[c], s);

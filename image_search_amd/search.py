@@ -97,6 +97,12 @@ class EmbeddingTable:
         check(lib().mi_knn_prefilter_stats(self._h, ctypes.byref(c), ctypes.byref(f)))
         return c.value, bool(f.value)
 
+    def prefilter_state(self):
+        """mi_knn_prefilter_state: the two-stage search's view of itself"""
+        out = (ctypes.c_uint32 * 4)()
+        check(lib().mi_knn_prefilter_state(self._h, out))
+        return {"skips_left": out[0], "consecutive_fallbacks": out[1], "searches_skipped": out[2], "scales_taken_at_rows": out[3]}
+
     def insert(self, embeddings: np.ndarray):
         """db.insert("image").content(rows) (clip.rs:125-137): ids are insertion ordinals."""
         e = _f32(embeddings).reshape(-1, self.dim)

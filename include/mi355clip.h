@@ -173,12 +173,21 @@ int mi_knn_set_base(mi_knn* t, uint64_t base);
  * next search, kept up to date by every later one) is scanned first, the rows that a rigorous error bound (1: data-
  * independent; 2: per row and query) cannot exclude are re-evaluated from the fp32 rows with the single-pass arithmetic:
  * same ids, same distance bits, a half (1) or a quarter (2) of the bytes per query.  Corpora that put more than 2^22
- * rows inside the bound fall back to the single pass on the device.  0 (default) frees the mirror. */
+ * rows inside the bound fall back to the single pass on the device.  0 (default) frees the mirror.
+ * "prefilter_adaptive" = 1 (default) / 0: the two-stage search watches itself — candidate counts and fallbacks are read
+ * back asynchronously; after two consecutive fallbacks, or when the median of the recent candidate counts exceeds 2^20, the
+ * next 64 single-query searches run the single pass alone (what such a corpus would pay anyway, without stage 1 on top),
+ * then stage 1 is probed again.  Results never change.  The channel scales of the byte mirror are taken again (and the
+ * mirror rebuilt, 10 ms per 10 M rows) when the table has grown 4x since they were taken. */
 int mi_knn_set_option(mi_knn* t, const char* key, int value);
 /* Of the most recent single-query search of this shard (waits for it): how many rows stage 2 re-evaluated, and whether the
  * single pass had to answer instead (then `candidates` is the count that did not fit).  Both 0 when the search did not
  * go through the prefilter (option off, k > 4096, fewer than 2^18 rows, batched searches). */
 int mi_knn_prefilter_stats(mi_knn* t, uint32_t* candidates, uint32_t* fell_back);
+/* The adaptive state (waits for the searches in flight): out = {searches for which stage 1 is still switched off,
+ * consecutive fallbacks seen, searches that skipped stage 1 so far, rows the table held when the byte mirror's channel
+ * scales were taken}. */
+int mi_knn_prefilter_state(mi_knn* t, uint32_t out[4]);
 int mi_knn_reserve(mi_knn* t, uint64_t rows); /* capacity hint; keeps contents */
 int mi_knn_size(const mi_knn* t, uint64_t* rows);
 

@@ -349,3 +349,68 @@ def test_bytes_narrow_rows_are_served_by_the_single_pass(built, bytes_mode):
     _same(*_both(t, q, 10))
     assert t.prefilter_stats() == (0, False)
     t.close()
+
+
+def test_repeated_fallbacks_switch_stage_one_off_for_a_while_and_probe_again(built):
+    """A corpus with > 2^22 rows inside the band used to pay stage 1 plus the single pass on EVERY query.  The search now
+    reads its own candidate count / fallback flag back asynchronously; after two fallbacks in a row the next 64 queries
+    run the single pass alone, then stage 1 is probed again.  Results are the single pass's throughout."""
+    import torch
+    gen = torch.Generator(device="cuda"); gen.manual_seed(12)
+    base = torch.randn((DIM,), device="cuda", generator=gen)
+    t = EmbeddingTable(DIM, 0)
+    t.reserve(4_400_000)
+    x = base[None, :].repeat(100_000, 1).contiguous()
+    for i in range(44):
+        t.insert_device(x.data_ptr(), 100_000, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    q = (base + 0.01 * torch.randn((DIM,), device="cuda", generator=gen)).cpu().numpy()
+    want = t.knn(q, 10)
+    t.set_option("prefilter", 1)
+    seen = []
+    for j in range(70):
+        _same(t.knn(q, 10), want)
+        seen.append(t.prefilter_stats())
+    # queries 0 and 1 fall back; 2 .. 65 skip stage 1 (no stats); 66 and 67 probe (and fall back) again; then skipping resumes
+    assert all(fb and c > (1 << 22) for c, fb in seen[:2]), seen[:3]
+    assert seen[2:66] == [(0, False)] * 64, seen[2:8]
+    assert all(fb for _, fb in seen[66:68]) and seen[68:] == [(0, False)] * 2, seen[64:]
+    st = t.prefilter_state()
+    assert st["searches_skipped"] == 66 and st["skips_left"] == 62, st
+    t.set_option("prefilter_adaptive", 0)                      # opt out: every query tries stage 1 again
+    for j in range(4):
+        _same(t.knn(q, 10), want)
+        assert t.prefilter_stats()[1] is True
+    t.close()
+
+
+def test_a_growing_table_keeps_its_mirror_and_refreshes_the_channel_scales_at_4x(built):
+    """any growth of the table's allocation used to throw the mirror away (a full fp32 pass inside the next
+    query).  Now the mirrored rows move to the larger buffers and only the new rows are converted; the byte mirror's
+    channel scales (taken from a sample spread over the table) are taken again once the table has grown 4x."""
+    t = EmbeddingTable(DIM, 0)
+    n0 = 300_000
+    t.insert_synthetic(21, 0, n0)                              # no reserve: every append below reallocates
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal(DIM).astype(np.float32)
+    t.set_option("prefilter", 2)
+    t.knn(q, 10)
+    assert t.prefilter_state()["scales_taken_at_rows"] == n0
+    rows = n0
+    for step in range(4):
+        extra = 250_000 if step < 3 else 500_000
+        t.insert_synthetic(22 + step, 0, extra)
+        rows += extra
+        got = t.knn(q, 100)
+        cand, fell_back = t.prefilter_stats()
+        assert not fell_back and cand >= 100
+        t.set_option("prefilter_adaptive", 1)                  # (no-op toggle: does not touch the mirror)
+        taken = t.prefilter_state()["scales_taken_at_rows"]
+        assert taken == (n0 if rows < 4 * n0 else rows), (rows, taken)
+        ref = EmbeddingTable(DIM, 0)                           # the same rows, single pass
+        ref.insert_synthetic(21, 0, n0)
+        for s2 in range(step + 1):
+            ref.insert_synthetic(22 + s2, 0, 250_000 if s2 < 3 else 500_000)
+        _same(got, ref.knn(q, 100))
+        ref.close()
+    t.close()

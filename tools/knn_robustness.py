@@ -9,6 +9,9 @@ Corpora (generated on the device with torch, appended with mi_knn_append_device)
               for a running threshold (WaveTopReg::offer sorts on every tile)
   ascending   the mirror image: the best rows come first, the threshold is tight from the start
   clusters    1000 centres, rows = centre + 0.1 noise, the query near one centre: ~N/1000 near-ties around the k-th
+  duplicates  5 M identical rows + 5 M iid rows, the query next to the duplicated row: > 2^22 rows inside any error band,
+              the two-stage search must fall back — with "prefilter_adaptive" (default) it stops paying stage 1 on top of
+              the single pass after two fallbacks (steady state over 200 queries is reported, adaptive on and off)
   iid again   the first corpus once more, last: separates the corpus from the order of the runs (allocation, clocks)
 Reported per corpus and k: ms per query (HIP events on the launch stream), GB/s over the table, ids checked
 against torch (fp32 matmul on the device is not the bit-exact oracle: only the id SETS must agree off ties)."""
@@ -38,6 +41,8 @@ def fill(table, kind, n, q, gen):
         elif kind == "clusters":
             c = torch.randint(0, 1000, (m,), device="cuda", generator=gen)
             x = centres[c] + 0.1 * x
+        elif kind == "duplicates" and lo < n // 2:
+            x = centres[3][None, :].repeat(m, 1).contiguous()
         table.insert_device(x.data_ptr(), m, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
     return centres
@@ -60,6 +65,8 @@ def main():
         centres = fill(t, kind, args.rows, q, gen)
         if kind == "clusters":
             q = centres[17] + 0.05 * torch.randn((768,), device="cuda", generator=gen)
+        if kind == "duplicates":
+            q = centres[3] + 0.01 * torch.randn((768,), device="cuda", generator=gen)
         for k in (10, 64, 1000):
             di = torch.empty((k,), dtype=torch.int64, device="cuda"); dd = torch.empty((k,), dtype=torch.float32, device="cuda")
             for _ in range(2):
@@ -86,6 +93,20 @@ def main():
                 out["results"][-1].update({"two_stage_ms_per_query": round(e0.elapsed_time(e1) / 10, 4), "rows_re_evaluated": cand,
                                            "fell_back_to_single_pass": fell_back,
                                            "same_ids_and_distance_bits": bool(torch.equal(ref_i, di) and torch.equal(ref_d.view(torch.int32), dd.view(torch.int32)))})
+                if kind == "duplicates":   # steady state of a corpus that defeats the mirror: 200 queries, adaptive on / off
+                    for adaptive in (1, 0):
+                        t.set_option("prefilter_adaptive", adaptive)
+                        for _ in range(4):
+                            t.knn_device(q.data_ptr(), 1, k, di.data_ptr(), dd.data_ptr(), st.cuda_stream)
+                            st.synchronize()
+                        e0.record(st)
+                        for _ in range(200):
+                            t.knn_device(q.data_ptr(), 1, k, di.data_ptr(), dd.data_ptr(), st.cuda_stream)
+                        e1.record(st); st.synchronize()
+                        out["results"][-1][f"steady_state_ms_adaptive_{adaptive}"] = round(e0.elapsed_time(e1) / 200, 4)
+                        out["results"][-1][f"same_bits_adaptive_{adaptive}"] = bool(torch.equal(ref_i, di) and torch.equal(ref_d.view(torch.int32), dd.view(torch.int32)))
+                    out["results"][-1]["state"] = t.prefilter_state()
+                    t.set_option("prefilter_adaptive", 1)
                 t.set_option("prefilter", 0)
             print(out["results"][-1], file=sys.stderr, flush=True)
         t.close()
