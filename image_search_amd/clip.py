@@ -158,6 +158,10 @@ class TextModel:
 
     __del__ = close
 
+    def set_option(self, key: str, value: int):
+        """text_fast = 0 sends a single query through the batched kernels too (A/B; include/mi355clip.h)."""
+        check(lib().mi_clip_set_option(self._h, key.encode(), int(value)))
+
     def embed(self, input_ids: np.ndarray) -> np.ndarray:
         ids = np.ascontiguousarray(input_ids, np.int32)
         if ids.ndim != 2 or ids.shape[1] != self.positions:

@@ -54,6 +54,11 @@ struct mi_clip {
     float* tok = nullptr;
     int *d_ids = nullptr, *d_rows = nullptr;
     size_t text_cap = 0;
+    // one text query as a captured hipGraph (forward_text_one is ~90 short kernels; launched one by one the host's launch
+    // calls cost more than the kernels): 0 = not yet run, 1 = ran once eagerly (function attributes are set), 2 = captured
+    int text_graph_state = 0;
+    hipGraph_t text_graph = nullptr;
+    hipGraphExec_t text_graph_exec = nullptr;
     // mi_clip_embed_images: two upload buffers for decoded images, the resize intermediate, a copy stream
     uint8_t* d_img_src[2] = {nullptr, nullptr};
     float* d_img_tmp = nullptr;
@@ -69,6 +74,8 @@ struct mi_clip {
     bool attn_shift = false;  // force the shifted (exact maximum) pass of attn32 — test hook
     bool full_last = false;   // compute the dead rows of the last layer too (A/B against the reference graph)
     bool split_tail = true;   // cut a short last round of GEMM tiles into quadrant tasks
+    bool text_fast = true;    // one text query (n == 1, CLIP-L text geometry, bf16): the skinny-GEMM path (vit.hip forward_text_one)
+    bool im2col_rows = true;  // bf16 tower: the LDS-staged patch gather (im2col_rows_kernel); 0 = the 4P-byte-run form (A/B)
     mi::WorkOrder order;          // serialises this handle's enqueued work across caller streams
     std::mutex mu;
 };
@@ -121,6 +128,10 @@ struct mi_knn {
     bool pref_ev_pending[PREF_RING] = {};
     uint32_t pref_hist[PREF_RING] = {};
     uint32_t pref_hist_n = 0, pref_consec = 0, pref_skip_left = 0;
+    // behind a skip window exactly two probes go out; until both have reported, later queries keep to the single pass
+    // (a caller that enqueues faster than the device answers must not queue dozens of probes behind the first two)
+    bool pref_probing = false;
+    uint32_t pref_probes_left = 0, pref_reports_due = 0;
     uint64_t pref_seq = 0, pref_skipped = 0;
     uint32_t* d_pref_rows = nullptr;   // [2 * PREF_CAP]: candidate rows, then their exact distance keys
     uint64_t* d_pref_keys = nullptr;   // [4096]: the k best keys of stage 2

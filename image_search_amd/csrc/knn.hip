@@ -154,8 +154,24 @@ bool prefilter_applies(const mi_knn* t, uint32_t k) {
     const uint32_t width = t->prefilter == 2 ? 256u : 128u;  // whole 256-byte chunks per mirror row
     return t->prefilter && (k <= 64 || (k <= 4096 && t->select_path)) && t->dim % width == 0 && t->rows >= PREF_MIN_ROWS;
 }
-uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s) {
-    ensure(t, (void**)&t->d_keys32, &t->keys32_cap, (size_t)t->cap, sizeof(uint32_t));
+// nq_batch = 4 or 8 (byte mirror, dim 768): query qi of a batch whose stage-1 keys come from ONE pass over the mirror —
+// the call for qi == 0 (d_q = the first of the nq_batch queries, contiguous) also runs that pass; every call runs its own
+// query's selects, collect and stage 2 on the shared workspace (stream order keeps the queries apart).
+template <int NCH>
+void launch_coarse8_batched(mi_knn* t, const uint8_t* m8, const float* d_q, float e0, uint32_t nq, uint32_t blocks, hipStream_t s) {
+    if constexpr (NCH == 12) {  // built for dim 768, the width of the reference's table (server/src/clip.rs:140-143)
+        if (nq == 8)
+            hipLaunchKernelGGL((knn_scan_coarse8_batched_kernel<NCH, 8>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8, t->d_cfac8,
+                               t->d_g8, t->rows, d_q, e0, t->d_keys32, (uint64_t)t->cap, t->d_rho8);
+        else
+            hipLaunchKernelGGL((knn_scan_coarse8_batched_kernel<NCH, 4>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8, t->d_cfac8,
+                               t->d_g8, t->rows, d_q, e0, t->d_keys32, (uint64_t)t->cap, t->d_rho8);
+    } else {
+        fail(MI_ERR_UNSUPPORTED, "the batched two-stage search is built for dim 768");
+    }
+}
+uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s, uint32_t nq_batch = 0, uint32_t qi = 0) {
+    ensure(t, (void**)&t->d_keys32, &t->keys32_cap, (size_t)t->cap * std::max(1u, nq_batch), sizeof(uint32_t));
     ensure(t, (void**)&t->d_sel, &t->sel_cap, (size_t)6 * SEL_BINS + 64, sizeof(uint32_t));
     ensure(t, (void**)&t->d_cand, &t->cand_keys, (size_t)4096, sizeof(uint64_t));
     ensure(t, (void**)&t->d_pref_rows, &t->pref_rows_cap, (size_t)2 * PREF_CAP, sizeof(uint32_t));  // rows, then their exact keys
@@ -174,7 +190,7 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s)
     if (bytes) {
         ensure_keep(t, (void**)&t->d_scale8, &t->scale8_cap, (size_t)t->cap, sizeof(float), (size_t)t->mirror_rows);
         ensure_keep(t, (void**)&t->d_cfac8, &t->cfac8_cap, (size_t)t->cap, sizeof(float), (size_t)t->mirror_rows);
-        ensure(t, (void**)&t->d_rho8, &t->rho8_cap, (size_t)4, sizeof(float));
+        ensure(t, (void**)&t->d_rho8, &t->rho8_cap, (size_t)8, sizeof(float));
         ensure(t, (void**)&t->d_g8, &t->g8_cap, (size_t)2 * t->dim, sizeof(float));
         if (!t->g8_ready) {  // the channel scales: RMS per dimension over a sample spread over the table (any positive values are correct)
             const uint64_t sample = std::min<uint64_t>(t->rows, 1u << 16), stride = t->rows / sample;
@@ -200,6 +216,7 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s)
     const float eps = 0x1p-8f + e0;                                  // bf16: 8 significant bits, unit roundoff 2^-8
     if (bytes) {
         uint8_t* m8 = reinterpret_cast<uint8_t*>(t->d_mirror);
+        const uint32_t* keys_q = t->d_keys32 + (size_t)qi * t->cap;
         switch (t->dim / 64) {
 #define MI_CASE(NCH)                                                                                                     \
     case NCH:                                                                                                            \
@@ -210,12 +227,15 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s)
                                t->rows, t->d_g8, m8, t->d_xx, t->d_scale8, t->d_cfac8);                                  \
             t->mirror_rows = t->rows;                                                                                    \
         }                                                                                                                \
-        hipLaunchKernelGGL((knn_scan_coarse8_kernel<NCH>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8,      \
-                           t->d_cfac8, t->d_g8, t->rows, d_q, e0, t->d_keys32, t->d_rho8);                               \
+        if (nq_batch == 0)                                                                                               \
+            hipLaunchKernelGGL((knn_scan_coarse8_kernel<NCH>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8,  \
+                               t->d_cfac8, t->d_g8, t->rows, d_q, e0, t->d_keys32, t->d_rho8);                           \
+        else if (qi == 0)                                                                                                \
+            launch_coarse8_batched<NCH>(t, m8, d_q, e0, nq_batch, blocks, s);                                            \
         for (int p = 0; p < 3; ++p)                                                                                      \
-            hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, p, t->d_sel, states); \
-        hipLaunchKernelGGL(knn_prefilter_collect8_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->d_cfac8, t->rows, k, \
-                           t->d_sel, states, t->d_rho8, e0, PREF_CAP, t->d_pref_rows, flags);                            \
+            hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb), dim3(256), 0, s, keys_q, t->rows, k, p, t->d_sel, states); \
+        hipLaunchKernelGGL(knn_prefilter_collect8_kernel, dim3(hb), dim3(256), 0, s, keys_q, t->d_cfac8, t->rows, k,     \
+                           t->d_sel, states, t->d_rho8 + qi, e0, PREF_CAP, t->d_pref_rows, flags);                       \
         hipLaunchKernelGGL((knn_rescore_kernel<NCH>), dim3(t->n_cu * 8), dim3(256), 0, s, t->table, d_q, t->d_pref_rows, \
                            flags, PREF_CAP, key32);                                                                      \
         break;
@@ -292,8 +312,21 @@ void select_pass(mi_knn* t, const float* d_q, uint32_t k, uint64_t* keys_out, hi
 }
 
 // ---- feedback of the two-stage search (handles.h: pref_*) -------------------------------------------------------
+void pref_window(mi_knn* t) {
+    t->pref_skip_left = mi_knn::PREF_SKIP;
+    t->pref_consec = 0;
+    t->pref_hist_n = 0;
+    t->pref_probing = false;
+}
 void pref_fold(mi_knn* t, uint32_t cand, uint32_t fell_back) {
     t->pref_consec = fell_back ? t->pref_consec + 1 : 0;
+    if (t->pref_probing) {  // the two probes behind a skip window: both must have reported before anything is decided
+        if (t->pref_reports_due && --t->pref_reports_due == 0) {
+            if (t->pref_consec >= 2) pref_window(t);
+            else t->pref_probing = false;
+        }
+        return;
+    }
     t->pref_hist[t->pref_hist_n++ % mi_knn::PREF_RING] = cand;
     bool skip = t->pref_consec >= 2;
     if (!skip && t->pref_hist_n >= 4) {  // the median of the last counts: a corpus that keeps stage 2 busy with > 2^20 rows per query
@@ -303,11 +336,7 @@ void pref_fold(mi_knn* t, uint32_t cand, uint32_t fell_back) {
         std::nth_element(v, v + m / 2, v + m);
         skip = v[m / 2] > (1u << 20);
     }
-    if (skip) {
-        t->pref_skip_left = mi_knn::PREF_SKIP;
-        t->pref_consec = 0;
-        t->pref_hist_n = 0;
-    }
+    if (skip) pref_window(t);
 }
 // fold what has arrived, oldest first, without waiting for anything
 void pref_poll(mi_knn* t) {
@@ -323,7 +352,10 @@ void pref_poll(mi_knn* t) {
 void pref_record(mi_knn* t, hipStream_t s) {
     if (!t->h_pref_ring) HIP_CHECK(hipHostMalloc((void**)&t->h_pref_ring, (size_t)mi_knn::PREF_RING * 2 * sizeof(uint32_t), hipHostMallocDefault));
     const int i = (int)(t->pref_seq % mi_knn::PREF_RING);
-    if (t->pref_ev_pending[i]) return;  // eight readbacks still in flight: this query goes unreported rather than waited for
+    if (t->pref_ev_pending[i]) {  // eight readbacks still in flight: this query goes unreported rather than waited for
+        if (t->pref_probing && t->pref_reports_due && --t->pref_reports_due == 0) t->pref_probing = false;
+        return;
+    }
     if (!t->pref_ev[i]) HIP_CHECK(hipEventCreateWithFlags(&t->pref_ev[i], hipEventDisableTiming));
     HIP_CHECK(hipMemcpyAsync(t->h_pref_ring + 2 * i, t->d_pref_flag, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipEventRecord(t->pref_ev[i], s));
@@ -336,12 +368,45 @@ void pref_reset(mi_knn* t) {
         t->pref_ev_pending[i] = false;
     }
     t->pref_hist_n = t->pref_consec = t->pref_skip_left = 0;
+    t->pref_probing = false;
+    t->pref_probes_left = t->pref_reports_due = 0;
 }
 
 // lists a register-path pass writes (the grid of one_pass<WaveTopReg>)
 uint32_t reg_pass_lists(const mi_knn* t) {
     const uint64_t n_tiles = (t->rows + 63) / 64;
     return 4 * std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 4, (n_tiles + 3) / 4));
+}
+
+// one query through the two stages (d_keys sized by the caller); nq_batch / qi: prefilter_pass
+void two_stage_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s, uint32_t nq_batch, uint32_t qi) {
+    // every workspace of this search at its final size BEFORE the first launch: growing one later would free a buffer
+    // that kernels already queued on `s` still use (ensure() only waits for EARLIER searches)
+    if (k <= 64) {
+        const uint32_t lists = reg_pass_lists(t);
+        ensure(t, (void**)&t->d_cand, &t->cand_keys, std::max<size_t>(4096, (size_t)lists * k), sizeof(uint64_t));
+        if (lists > 64) ensure(t, (void**)&t->d_tmp, &t->tmp_keys, (size_t)((lists + 31) / 32) * k, sizeof(uint64_t));
+    }
+    const uint32_t* fallback = prefilter_pass(t, d_q, k, s, nq_batch, qi);
+    // the single pass, every kernel of it returning at once unless *fallback
+    if (k <= 64) one_pass<WaveTopReg>(t, d_q, k, nullptr, t->d_keys, s, fallback);
+    else select_pass(t, d_q, k, t->d_keys, s, fallback);
+    hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, id_map(t),
+                       d_idx, d_dist, (size_t)0, (size_t)0, t->d_pref_keys, fallback);
+    HIP_CHECK(hipGetLastError());
+}
+
+// nq = 4 or 8 queries (contiguous at d_q) through the two stages with ONE pass over the byte mirror; bit-identical to nq
+// single searches (the per-(row, query) arithmetic of stage 1 is the single kernel's; stage 2 is the single search's own)
+bool batched_two_stage_applies(const mi_knn* t, uint32_t k) {
+    return t->prefilter == 2 && t->dim == 768 && prefilter_applies(t, k) && !(t->pref_adaptive && (t->pref_skip_left || t->pref_probing));
+}
+void search_batched_two_stage(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
+    const uint32_t passes = (k + 1023) / 1024;
+    ensure(t, (void**)&t->d_keys, &t->keys_cap, (size_t)std::max<uint32_t>(passes * 1024, 4096), sizeof(uint64_t));
+    t->last_prefiltered = true;
+    for (uint32_t qi = 0; qi < nq; ++qi)
+        two_stage_one(t, d_q + (size_t)qi * t->dim, k, d_idx + (size_t)qi * k, d_dist + (size_t)qi * k, s, nq, qi);
 }
 
 void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
@@ -357,26 +422,16 @@ void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float*
     if (t->last_prefiltered && t->pref_adaptive) {
         pref_poll(t);
         if (t->pref_skip_left) {  // this corpus has been defeating the mirror: the single pass alone, for a while
-            --t->pref_skip_left;
+            if (--t->pref_skip_left == 0) { t->pref_probing = true; t->pref_probes_left = t->pref_reports_due = 2; t->pref_consec = 0; }
             ++t->pref_skipped;
             t->last_prefiltered = false;
+        } else if (t->pref_probing) {
+            if (t->pref_probes_left) --t->pref_probes_left;             // one of the two probes
+            else { ++t->pref_skipped; t->last_prefiltered = false; }    // their reports are still on the way
         }
     }
     if (t->last_prefiltered) {
-        // every workspace of this search at its final size BEFORE the first launch: growing one later would free a buffer
-        // that kernels already queued on `s` still use (ensure() only waits for EARLIER searches)
-        if (k <= 64) {
-            const uint32_t lists = reg_pass_lists(t);
-            ensure(t, (void**)&t->d_cand, &t->cand_keys, std::max<size_t>(4096, (size_t)lists * k), sizeof(uint64_t));
-            if (lists > 64) ensure(t, (void**)&t->d_tmp, &t->tmp_keys, (size_t)((lists + 31) / 32) * k, sizeof(uint64_t));
-        }
-        const uint32_t* fallback = prefilter_pass(t, d_q, k, s);
-        // the single pass, every kernel of it returning at once unless *fallback
-        if (k <= 64) one_pass<WaveTopReg>(t, d_q, k, nullptr, t->d_keys, s, fallback);
-        else select_pass(t, d_q, k, t->d_keys, s, fallback);
-        hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, id_map(t),
-                           d_idx, d_dist, (size_t)0, (size_t)0, t->d_pref_keys, fallback);
-        HIP_CHECK(hipGetLastError());
+        two_stage_one(t, d_q, k, d_idx, d_dist, s, 0, 0);
         if (t->pref_adaptive) pref_record(t, s);
         return;
     }
@@ -788,6 +843,12 @@ int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint3
         uint32_t u = 0;
         while (u < nq) {
             const uint32_t left = nq - u;
+            if (left >= 4 && batched_two_stage_applies(t, k)) {  // one pass over the byte mirror serves 8 (or 4) queries
+                const uint32_t b2 = left >= 8 ? 8 : 4;
+                search_batched_two_stage(t, d_q + (size_t)u * t->dim, b2, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
+                u += b2;
+                continue;
+            }
             const uint32_t b = (k <= 64 && t->rows && t->dim == 768) ? (left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1) : 1;
             if (b == 1) search_one(t, d_q + (size_t)u * t->dim, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
             else search_batched(t, d_q + (size_t)u * t->dim, b, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
@@ -831,6 +892,12 @@ int mi_knn_search(mi_knn* t, const float* q, uint32_t nq, uint32_t k, uint64_t* 
             uint32_t u = 0;
             while (u < ng) {
                 const uint32_t left = ng - u;
+                if (left >= 4 && batched_two_stage_applies(t, k)) {
+                    const uint32_t b2 = left >= 8 ? 8 : 4;
+                    search_batched_two_stage(t, t->d_q + (size_t)u * t->dim, b2, k, t->d_idx + (size_t)u * k, t->d_dist + (size_t)u * k, t->stream);
+                    u += b2;
+                    continue;
+                }
                 const uint32_t b = (k <= 64 && t->rows && t->dim == 768) ? (left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1) : 1;
                 if (b == 1) search_one(t, t->d_q + (size_t)u * t->dim, k, t->d_idx + (size_t)u * k, t->d_dist + (size_t)u * k, t->stream);
                 else search_batched(t, t->d_q + (size_t)u * t->dim, b, k, t->d_idx + (size_t)u * k, t->d_dist + (size_t)u * k, t->stream);

@@ -787,6 +787,105 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_kernel(const uint8_t*
     }
 }
 
+// stage 1 on the byte mirror for NQ = 4 or 8 queries in ONE pass over the mirror (the throughput form of the two-stage
+// search).  The loads are those of knn_scan_coarse8_kernel — the four 16-lane groups of a wave fetch four different rows
+// per instruction — but each GROUP keeps its own query (NQ = 8: two): a fetched row is handed round the groups by
+// ds_bpermute (12 dwords per lane and row at dim 768, cheap beside the 48 byte conversions), so every group meets every
+// row with its own query.  Per (row, query) the arithmetic is knn_scan_coarse8_kernel's, operation for operation: the
+// same four fmaf chains, pairwise sum and butterfly, hence the same upper-bound keys and the same candidates as NQ single
+// searches.  all_keys: [NQ][key_stride], rho_out: [NQ].
+template <int NCH, int NQ>
+__global__ __launch_bounds__(256, 2) void knn_scan_coarse8_batched_kernel(const uint8_t* __restrict__ mirror, const float* __restrict__ xx,
+                                                                        const float* __restrict__ scale, const float* __restrict__ cfac,
+                                                                        const float* __restrict__ gch, uint64_t n_rows,
+                                                                        const float* __restrict__ q, float e0,
+                                                                        uint32_t* __restrict__ all_keys, uint64_t key_stride,
+                                                                        float* __restrict__ rho_out) {
+    static_assert(NCH % 4 == 0 && (NQ == 4 || NQ == 8), "whole 256-byte chunks; one or two queries per 16-lane group");
+    constexpr int DIM = NCH * 64, U = NCH / 4, QPG = NQ / 4;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const uint32_t wave = blockIdx.x * 4 + wib, n_waves = gridDim.x * 4;
+    float qf[QPG][U][16];
+    float sq[QPG], rho[QPG], qsum128[QPG];
+#pragma unroll
+    for (int c = 0; c < QPG; ++c) {
+        const float* qq = q + (size_t)(g + 4 * c) * DIM;  // group g: query g (and g + 4)
+        float s2 = 0.0f, s1 = 0.0f, ss = 0.0f;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float qe = qq[256 * u + 16 * i + e];
+                s2 = __builtin_fmaf(qe, qe, s2);
+                qf[c][u][e] = qe * gch[256 * u + 16 * i + e];
+                s1 += fabsf(qf[c][u][e]);
+                ss += qf[c][u][e];
+            }
+        sq[c] = sqrtf(row16_sum(s2));
+        rho[c] = row16_sum(s1) / sq[c] * 1.000001f;
+        qsum128[c] = 128.0f * row16_sum(ss);
+        if (blockIdx.x == 0 && wib == 0 && i == 0) rho_out[g + 4 * c] = rho[c];
+    }
+    const uint64_t n_tiles = (n_rows + 63) >> 6;
+    auto load_row = [&](u32x4 (&x)[U], uint64_t r) {
+        r = r < n_rows ? r : n_rows - 1;
+        const u32x4* p = reinterpret_cast<const u32x4*>(mirror + r * DIM) + i;
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p + 16 * u);
+    };
+    for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
+        float mydot[QPG][4];  // [query of this group][source group sg]: lane i keeps row 16 sg + i of the tile
+        const uint64_t row0 = (tile << 6) + 16 * g;
+        u32x4 xr[4][U];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) load_row(xr[d], row0 + d);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            if (it + 3 < 16) load_row(xr[(it + 3) & 3], row0 + it + 3);
+            const u32x4(&own)[U] = xr[it & 3];
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {  // the row group sg fetched in this step: tile row 16 sg + it
+                uint32_t w[U][4];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t o[4] = {own[u].x, own[u].y, own[u].z, own[u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[u][j] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (16 * sg + i), (int)o[j]);
+                }
+#pragma unroll
+                for (int c = 0; c < QPG; ++c) {
+                    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            a[0] = __builtin_fmaf(qf[c][u][4 * j + 0], (float)(w[u][j] & 0xFFu), a[0]);
+                            a[1] = __builtin_fmaf(qf[c][u][4 * j + 1], (float)((w[u][j] >> 8) & 0xFFu), a[1]);
+                            a[2] = __builtin_fmaf(qf[c][u][4 * j + 2], (float)((w[u][j] >> 16) & 0xFFu), a[2]);
+                            a[3] = __builtin_fmaf(qf[c][u][4 * j + 3], (float)(w[u][j] >> 24), a[3]);
+                        }
+                    const float d = row16_sum((a[0] + a[1]) + (a[2] + a[3]));
+                    if (i == it) mydot[c][sg] = d;
+                }
+            }
+        }
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            const uint64_t r = (tile << 6) + 16 * sg + i;
+            if (r < n_rows) {
+                const float s = xx[r], sc = scale[r], cf = cfac[r];
+#pragma unroll
+                for (int c = 0; c < QPG; ++c) {
+                    const float dot = sc * (mydot[c][sg] - qsum128[c]);
+                    const float upper = (1.0f - dot / (sq[c] * sqrtf(s))) + (cf * rho[c] + e0);
+                    all_keys[(size_t)(g + 4 * c) * key_stride + r] = s < 0.0f ? PREF_MARK : dist_to_u32(upper);
+                }
+            }
+        }
+    }
+}
+
 // the candidates of the 8-bit stage: rows whose LOWER bound U_r - 2 eps_r is not beyond the k-th smallest upper bound
 __global__ __launch_bounds__(256) void knn_prefilter_collect8_kernel(const uint32_t* __restrict__ keys, const float* __restrict__ cfac,
                                                                      uint64_t n_rows, uint32_t k, const uint32_t* __restrict__ hist,

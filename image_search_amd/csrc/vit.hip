@@ -417,6 +417,9 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
         const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65535 * 4);
         if (m->precision == MI_PRECISION_F32)
             hipLaunchKernelGGL((im2col_kernel<float>), dim3(blocks), dim3(256), 0, q.s, q.img, (float*)q.a->col, (int)q.n, m->grid, m->patch, m->image, m->Kp);
+        else if (m->im2col_rows && m->image % 4 == 0 && (3 * m->patch * m->patch) % 4 == 0 && m->Kp % 4 == 0 && (size_t)3 * m->patch * m->image * 4 <= 64 * 1024)
+            hipLaunchKernelGGL(im2col_rows_kernel, dim3((unsigned)(q.n * m->grid)), dim3(256), (size_t)3 * m->patch * m->image * 4, q.s, q.img,
+                               (bf16_t*)q.a->col, m->grid, m->patch, m->image, m->Kp);
         else
             hipLaunchKernelGGL((im2col_kernel<bf16_t>), dim3(blocks), dim3(256), 0, q.s, q.img, (bf16_t*)q.a->col, (int)q.n, m->grid, m->patch, m->image, m->Kp);
         HIP_CHECK(hipGetLastError());
@@ -519,10 +522,18 @@ void ensure_copy_stream(mi_clip* m) {
 }
 
 // ---- text tower: workspace and forward (fp32) -------------------------------------------
+void drop_text_graph(mi_clip* m) {
+    if (m->text_graph_exec) (void)hipGraphExecDestroy(m->text_graph_exec);
+    if (m->text_graph) (void)hipGraphDestroy(m->text_graph);
+    m->text_graph_exec = nullptr; m->text_graph = nullptr;
+    m->text_graph_state = 0;
+}
+
 void ensure_text_workspace(mi_clip* m, size_t n) {
     if (n <= m->text_cap) return;
     own_stream(m);
     m->order.sync();
+    drop_text_graph(m);  // it holds the addresses of the buffers freed here
     for (void* p : m->ws) HIP_CHECK(hipFree(p));
     m->ws.clear();
     m->text_cap = 0;
@@ -542,6 +553,7 @@ void ensure_text_workspace(mi_clip* m, size_t n) {
     if (m->precision == MI_PRECISION_BF16) {
         m->act[0].delta = (bf16_t*)bytes(Ma * m->D * 2);
         m->act[0].delta2 = (bf16_t*)bytes(Ma * m->D * 2);
+        m->act[0].patch = (float*)bytes((size_t)(m->FF / SKINNY_KC + 1) * SKINNY_ROWS * m->D * 4);  // fc2 partial slabs of forward_text_one
     }
     m->d_ids = (int*)bytes(Ma * sizeof(int));
     m->d_rows = (int*)bytes(n * sizeof(int));
@@ -550,8 +562,75 @@ void ensure_text_workspace(mi_clip* m, size_t n) {
     m->text_cap = n;
 }
 
+// ONE sequence (the request path: server/src/clip.rs:19-23 embeds one query per search) on the skinny GEMMs of
+// vit_kernels.h: the same graph and the same bf16 rounding points as forward_text, except that fc2's output reaches the
+// residual stream as fp32 partial sums instead of a bf16 delta.  Geometry of the CLIP-L text tower only (D = 768 = one K
+// chunk, FF = 4 chunks, at most 80 positions); everything else takes forward_text.
+bool text_one_applies(const mi_clip* m, size_t n) {
+    return m->text_fast && m->precision == MI_PRECISION_BF16 && !m->split_ln && n == 1 && m->D == SKINNY_KC && m->FF == 4 * SKINNY_KC &&
+           m->S <= SKINNY_ROWS && m->D % 16 == 0 && !m->layers.empty();
+}
+void forward_text_one(mi_clip* m, hipStream_t s) {
+    const int D = m->D, S = m->S, FF = m->FF;
+    mi_clip::Act& a = m->act[0];
+    bf16_t *y = (bf16_t*)a.y, *qkv = (bf16_t*)a.qkv, *h = (bf16_t*)a.h;
+    float* slabs = a.patch;  // [4][SKINNY_ROWS][D] fp32
+    const unsigned lb = (unsigned)((S + 3) / 4);
+    constexpr int VEC = 4, NT = 3;  // D = 768
+    const bf16_t* d1 = nullptr;
+    const float* b2 = nullptr;
+    const int* ids = m->d_ids;      // first layer: LN1 also assembles x = token + position embeddings
+    int n_slabs = 0;
+    for (const Layer& ly : m->layers) {
+        // LN1 also lands the previous layer's residual adds: x += out_proj delta + fc2 partial sums + fc2 bias
+        hipLaunchKernelGGL((ln_slab_kernel<VEC, NT>), dim3(lb), dim3(256), 0, s, a.x, d1, slabs, n_slabs, b2, y, ly.ln1w, ly.ln1b, S, m->eps, 1,
+                           ids, m->tok, m->pos);
+        ids = nullptr;
+        hipLaunchKernelGGL((skinny_gemm_kernel<SKINNY_BIAS>), dim3(3 * D / 16, 1), dim3(256), 0, s, y, D, (const bf16_t*)ly.wqkv, D, ly.bqkv, qkv, 3 * D);
+        attention(m, qkv, y, 1, s);
+        hipLaunchKernelGGL((skinny_gemm_kernel<SKINNY_BIAS>), dim3(D / 16, 1), dim3(256), 0, s, y, D, (const bf16_t*)ly.wo, D, ly.bo, a.delta, D);
+        hipLaunchKernelGGL((ln_slab_kernel<VEC, NT>), dim3(lb), dim3(256), 0, s, a.x, a.delta, slabs, 0, nullptr, y, ly.ln2w, ly.ln2b, S, m->eps, 0,
+                           (const int*)nullptr, (const float*)nullptr, (const float*)nullptr);
+        hipLaunchKernelGGL((skinny_gemm_kernel<SKINNY_BIAS_QGELU>), dim3(FF / 16, 1), dim3(256), 0, s, y, D, (const bf16_t*)ly.w1, D, ly.b1, h, FF);
+        hipLaunchKernelGGL((skinny_gemm_kernel<SKINNY_SLAB>), dim3(D / 16, FF / SKINNY_KC), dim3(256), 0, s, h, FF, (const bf16_t*)ly.w2, FF, nullptr, slabs, D);
+        d1 = a.delta; b2 = ly.b2; n_slabs = FF / SKINNY_KC;
+    }
+    // the EOS row: the last layer's residual adds, final_layer_norm and the projection, fp32, one launch
+    hipLaunchKernelGGL((text_head_one_kernel<VEC, NT>), dim3((unsigned)((m->E + 3) / 4)), dim3(256), 0, s, a.x, d1, slabs, n_slabs, b2, m->post_w,
+                       m->post_b, m->proj, m->d_out, m->d_ids, S, m->E, m->eps);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ... replayed as ONE graph launch from the third call on (first call: eager, which also sets the kernels' function
+// attributes; second: captured while it is enqueued; `s` must be the handle's own stream)
+void forward_text_one_graphed(mi_clip* m, hipStream_t s) {
+    if (m->text_graph_state == 2) {
+        HIP_CHECK(hipGraphLaunch(m->text_graph_exec, s));
+        return;
+    }
+    if (m->text_graph_state == 0) {
+        forward_text_one(m, s);
+        m->text_graph_state = 1;
+        return;
+    }
+    HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    try {
+        forward_text_one(m, s);
+    } catch (...) {
+        hipGraph_t dead = nullptr;
+        (void)hipStreamEndCapture(s, &dead);
+        if (dead) (void)hipGraphDestroy(dead);
+        throw;
+    }
+    HIP_CHECK(hipStreamEndCapture(s, &m->text_graph));
+    HIP_CHECK(hipGraphInstantiate(&m->text_graph_exec, m->text_graph, nullptr, nullptr, 0));
+    m->text_graph_state = 2;
+    HIP_CHECK(hipGraphLaunch(m->text_graph_exec, s));
+}
+
 // n sequences whose ids are in m->d_ids -> m->d_out [n,E]
 void forward_text(mi_clip* m, size_t n, hipStream_t s) {
+    if (text_one_applies(m, n)) return forward_text_one_graphed(m, s);
     const int D = m->D, S = m->S, FF = m->FF;
     const size_t M = n * S;
     mi_clip::Act& a = m->act[0];
@@ -597,6 +676,7 @@ void free_model(mi_clip* m) {
         if (m->d_img_src[b]) (void)hipFree(m->d_img_src[b]);
     }
     if (m->d_img_tmp) (void)hipFree(m->d_img_tmp);
+    drop_text_graph(m);
     for (void* p : m->allocs) (void)hipFree(p);
     for (void* p : m->ws) (void)hipFree(p);
     delete m;
@@ -642,6 +722,8 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         if (k == "full_last") m->full_last = value != 0;
         else if (k == "attn_shift") m->attn_shift = value != 0;
         else if (k == "split_tail") m->split_tail = value != 0;
+        else if (k == "im2col_rows") m->im2col_rows = value != 0;
+        else if (k == "text_fast") m->text_fast = value != 0;
         else if (k == "max_batch") {
             if (value < 1) fail(MI_ERR_INVALID, "max_batch must be >= 1");
             m->max_batch = (size_t)value;
@@ -655,7 +737,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, im2col_rows, text_fast, max_batch, parts)", key);
     });
 }
 
@@ -681,6 +763,7 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         if (const char* e = std::getenv("MI_CLIP_FULL_LAST")) m->full_last = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_CLIP_ATTN")) m->attn_ver = std::atoi(e) == 1 ? 1 : 2;  // fixed at load: decides the q scale
         if (const char* e = std::getenv("MI_GEMM_SPLIT")) m->split_tail = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MI_CLIP_IM2COL")) m->im2col_rows = std::atoi(e) != 0;
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         m->n_cu = prop.multiProcessorCount;
@@ -707,6 +790,7 @@ int mi_clip_load_text(const char* weights_path, int device, int precision, mi_cl
         m->precision = precision;
         m->text = true;
         m->parts = 1;
+        if (const char* e = std::getenv("MI_CLIP_TEXT_FAST")) m->text_fast = std::atoi(e) != 0;  // A/B hook, read at load
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         m->n_cu = prop.multiProcessorCount;

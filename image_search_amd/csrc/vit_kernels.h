@@ -118,6 +118,37 @@ __global__ void im2col_kernel(const float* __restrict__ img, T* __restrict__ col
     }
 }
 
+// The same gather for the bf16 tower, through LDS: one workgroup per (image, patch row).  The 3 P image rows of that
+// patch row are read as whole 4 HW-byte rows (float4, coalesced) into LDS; every patch's 3 P P columns leave as ONE
+// contiguous run of the col row (1 176 bytes at P = 14), 8 bytes per thread.  im2col_kernel moves 4 P-byte runs on both
+// sides and reaches 1.8 TB/s (130 us per 256 images); this one is bound by its 238 MB of traffic.
+// Needs HW % 4 == 0, (3 P P) % 4 == 0, Kp % 4 == 0; LDS = 3 P HW floats.
+__global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restrict__ img, bf16_t* __restrict__ col, int G, int P, int HW,
+                                                          int Kp) {
+    extern __shared__ __attribute__((aligned(16))) float im2col_lds[];
+    const int b = blockIdx.x / G, gy = blockIdx.x - b * G;
+    const int rows = 3 * P, q4 = HW >> 2;
+    for (int i = threadIdx.x; i < rows * q4; i += 256) {
+        const int rw = i / q4, x4 = i - rw * q4;  // rw = c * P + py
+        const int c = rw / P, py = rw - c * P;
+        const v4f v = *reinterpret_cast<const v4f*>(img + (((size_t)b * 3 + c) * HW + (size_t)(gy * P + py)) * HW + 4 * x4);
+        *reinterpret_cast<v4f*>(im2col_lds + (size_t)rw * HW + 4 * x4) = v;
+    }
+    __syncthreads();
+    const int per = 3 * P * P, g4 = per >> 2;
+    for (int i = threadIdx.x; i < G * g4; i += 256) {
+        const int gx = i / g4, j = i - gx * g4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * j + e, rw = k / P, px = k - rw * P;  // rw = c * P + py again: k = (c P + py) P + px
+            v[e] = im2col_lds[(size_t)rw * HW + gx * P + px];
+        }
+        bf16_t* dst = col + (((size_t)b * G + gy) * G + gx) * (size_t)Kp + 4 * j;
+        *reinterpret_cast<v2u*>(dst) = (v2u){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    }
+}
+
 // ------------------------------------------------------------------ LayerNorm
 // One wave per row, row held in registers, two-pass mean / biased variance,
 // y = d / sqrt(var + eps) * w + b  (the decomposed opset-16 form the reference
@@ -280,6 +311,165 @@ __global__ void scatter_rows_kernel(const T* __restrict__ src, T* __restrict__ d
         const size_t r = i / per, c = i % per;
         reinterpret_cast<v4u*>(dst + r * stride_rows * ld)[c] = reinterpret_cast<const v4u*>(src + r * D)[c];
     }
+}
+
+// ------------------------------------------------------------------ one text query: skinny GEMMs
+// A text query is 77 token rows (server/src/clip.rs:19-23 sits in front of every search).  On those shapes a tiled GEMM
+// is a latency chain: three to a dozen workgroups, each walking K in steps that pay an HBM round trip apiece (~10 us
+// per kernel, ~90 kernels per query).  Here every workgroup owns 16 output columns and ONE K chunk of 768, all of whose
+// operand loads (6 weight + 30 activation fragments per wave, 16 bytes per lane each) are in flight before the first
+// MFMA: 48 - 192 workgroups stream the layer's weights side by side and a kernel lasts about one memory round trip.
+//   C^T = W X^T on MFMA 16x16x32 (A = weights [n][k], B = activations [m][k], both K-contiguous, straight from global
+//   memory in fragment order): a lane ends up with 4 consecutive output columns of one token row.  The four waves of a
+//   workgroup split the K chunk (192 each) and meet in LDS; the sum runs wave 0..3, fixed order.
+//   grid = (N / 16, K / 768): blockIdx.y > 0 only with EPI_SLAB (fc2, K = 3072), whose fp32 partial slabs
+//   [K/768][SKINNY_ROWS][N] are summed — again in fixed order — by ln_slab_kernel.
+enum { SKINNY_BIAS = 0, SKINNY_BIAS_QGELU = 1, SKINNY_SLAB = 2 };
+constexpr int SKINNY_MT = 5, SKINNY_ROWS = 16 * SKINNY_MT, SKINNY_KC = 768;  // 80 token rows (77 live), K per workgroup
+template <int EPI>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W, int ldw,
+                                                          const float* __restrict__ bias, void* __restrict__ out, int ldo) {
+    __shared__ v4f red[4][SKINNY_MT][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int k0 = blockIdx.y * SKINNY_KC + wave * (SKINNY_KC / 4) + 8 * (lane >> 4);
+    const bf16_t* wp = W + (size_t)(n0 + (lane & 15)) * ldw + k0;
+    const bf16_t* xp = X + (size_t)(lane & 15) * ldx + k0;
+    bf16x8 a[6], b[SKINNY_MT][6];
+    // this thread's epilogue items (threadIdx.x and threadIdx.x + 256) share one column group: its bias is fetched now,
+    // beside the operands, not behind the reduction (one more memory round trip in a kernel that lasts about three)
+    v4f bias4 = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (EPI != SKINNY_SLAB) bias4 = *reinterpret_cast<const v4f*>(bias + n0 + 4 * (lane >> 4));
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(wp + 32 * ks);
+#pragma unroll
+    for (int mt = 0; mt < SKINNY_MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) b[mt][ks] = *reinterpret_cast<const bf16x8*>(xp + (size_t)(16 * mt) * ldx + 32 * ks);
+    v4f acc[SKINNY_MT];
+#pragma unroll
+    for (int mt = 0; mt < SKINNY_MT; ++mt) acc[mt] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < SKINNY_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], b[mt][ks], acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < SKINNY_MT; ++mt) red[wave][mt][lane] = acc[mt];
+    __syncthreads();
+    for (int item = threadIdx.x; item < SKINNY_MT * 64; item += 256) {
+        const int mt = item >> 6, l = item & 63;
+        v4f v = red[0][mt][l];
+        v += red[1][mt][l]; v += red[2][mt][l]; v += red[3][mt][l];
+        const int row = 16 * mt + (l & 15), col = n0 + 4 * (l >> 4);
+        if constexpr (EPI == SKINNY_SLAB) {
+            *reinterpret_cast<v4f*>(static_cast<float*>(out) + ((size_t)blockIdx.y * SKINNY_ROWS + row) * ldo + col) = v;
+        } else {
+            v += bias4;
+            if constexpr (EPI == SKINNY_BIAS_QGELU) {
+                v.x = quick_gelu<true>(v.x); v.y = quick_gelu<true>(v.y); v.z = quick_gelu<true>(v.z); v.w = quick_gelu<true>(v.w);
+            }
+            *reinterpret_cast<v2u*>(static_cast<bf16_t*>(out) + (size_t)row * ldo + col) = (v2u){pack2bf(v.x, v.y), pack2bf(v.z, v.w)};
+        }
+    }
+}
+
+// LayerNorm behind the skinny GEMMs: x[row] (+ d1[row], the out_proj output, bf16) (+ the n_slabs fc2 partial slabs, in
+// order, + fc2's bias) -> optionally written back -> y[row] = LN(that).  One wave per row, as ln_kernel and with its
+// arithmetic (LnRow), but the affine parameters are requested before the reductions: in a kernel this short a dependent
+// load is a fifth of its duration.  ids != null (first layer): x[row] = token_embedding[ids[row]] + position_embedding[row].
+template <int VEC, int NT>
+struct LnSlabRow {
+    LnRow<VEC, NT> r;
+    __device__ __forceinline__ void gather(const float* __restrict__ x, const bf16_t* __restrict__ d1, const float* __restrict__ slabs,
+                                           int n_slabs, const float* __restrict__ bias2, const int* __restrict__ ids,
+                                           const float* __restrict__ tok, const float* __restrict__ pos, int row, int lane) {
+        constexpr int D = 64 * VEC * NT;
+        if (ids) {
+            r.load(tok + (size_t)ids[row] * D, lane);
+            r.add(pos + (size_t)row * D, lane);
+        } else {
+            r.load(x + (size_t)row * D, lane);
+        }
+        if (d1) r.add_bf16(d1 + (size_t)row * D, lane);
+        for (int s = 0; s < n_slabs; ++s) r.add(slabs + ((size_t)s * SKINNY_ROWS + row) * D, lane);
+        if (n_slabs) r.add(bias2, lane);
+    }
+    // LnRow::normalize with w and b already in registers
+    __device__ __forceinline__ void normalize(const float (&ww)[VEC * NT], const float (&bb)[VEC * NT], float eps) {
+        constexpr float inv = 1.0f / (64 * VEC * NT);
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < VEC * NT; ++j) s += r.v[j];
+        const float mean = wave_sum(s) * inv;
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < VEC * NT; ++j) { r.v[j] -= mean; q = __builtin_fmaf(r.v[j], r.v[j], q); }
+        const float sd = sqrtf(wave_sum(q) * inv + eps);
+#pragma unroll
+        for (int j = 0; j < VEC * NT; ++j) r.v[j] = r.v[j] / sd * ww[j] + bb[j];
+    }
+};
+template <int VEC, int NT>
+__global__ __launch_bounds__(256) void ln_slab_kernel(float* __restrict__ x, const bf16_t* __restrict__ d1, const float* __restrict__ slabs,
+                                                      int n_slabs, const float* __restrict__ bias2, bf16_t* __restrict__ y,
+                                                      const float* __restrict__ w, const float* __restrict__ b, int rows, float eps,
+                                                      int write_back, const int* __restrict__ ids, const float* __restrict__ tok,
+                                                      const float* __restrict__ pos) {
+    constexpr int D = 64 * VEC * NT;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float ww[VEC * NT], bb[VEC * NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        ld_vec<VEC>(&ww[t * VEC], w + (t * 64 + lane) * VEC);
+        ld_vec<VEC>(&bb[t * VEC], b + (t * 64 + lane) * VEC);
+    }
+    LnSlabRow<VEC, NT> q;
+    q.gather(x, d1, slabs, n_slabs, bias2, ids, tok, pos, row, lane);
+    if (write_back) q.r.store(x + (size_t)row * D, lane);
+    q.normalize(ww, bb, eps);
+    q.r.store(y + (size_t)row * D, lane);
+}
+
+// The end of one text query in one launch: the EOS row (first maximum of the ids: the EOS token is the largest id) with
+// the last layer's residual adds, final_layer_norm, and the bias-free projection — out[e] = proj[e] . LN(x_eos), fp32
+// throughout (the stored vector is never rounded to bf16 behind the last residual add).  One wave per output element;
+// every wave redoes the row's LayerNorm (3 KB from L2) rather than wait for another kernel to do it once.
+template <int VEC, int NT>
+__global__ __launch_bounds__(256) void text_head_one_kernel(const float* __restrict__ x, const bf16_t* __restrict__ d1,
+                                                            const float* __restrict__ slabs, int n_slabs, const float* __restrict__ bias2,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* __restrict__ proj, float* __restrict__ out,
+                                                            const int* __restrict__ ids, int S, int E, float eps) {
+    constexpr int D = 64 * VEC * NT;
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= E) return;
+    float pw[VEC * NT], ww[VEC * NT], bb[VEC * NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        ld_vec<VEC>(&pw[t * VEC], proj + (size_t)e * D + (t * 64 + lane) * VEC);
+        ld_vec<VEC>(&ww[t * VEC], w + (t * 64 + lane) * VEC);
+        ld_vec<VEC>(&bb[t * VEC], b + (t * 64 + lane) * VEC);
+    }
+    // argmax over the ids, first maximum: key = (id << 8) | (255 - position), S <= 128
+    long long best = -1;
+    for (int j = lane; j < S; j += 64) best = max(best, ((long long)ids[j] << 8) | (long long)(255 - j));
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int lo = __shfl_xor((int)best, o, 64), hi = __shfl_xor((int)(best >> 32), o, 64);
+        best = max(best, ((long long)hi << 32) | (unsigned int)lo);
+    }
+    const int row = 255 - (int)(best & 0xff);
+    LnSlabRow<VEC, NT> q;
+    q.gather(x, d1, slabs, n_slabs, bias2, nullptr, nullptr, nullptr, row, lane);
+    q.normalize(ww, bb, eps);
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < VEC * NT; ++j) acc = __builtin_fmaf(q.r.v[j], pw[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) out[e] = acc;
 }
 
 // ------------------------------------------------------------------ text tower front / pooling index

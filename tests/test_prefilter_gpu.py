@@ -414,3 +414,36 @@ def test_a_growing_table_keeps_its_mirror_and_refreshes_the_channel_scales_at_4x
         _same(got, ref.knn(q, 100))
         ref.close()
     t.close()
+
+
+@pytest.mark.parametrize("k", [1, 10, 64, 1000])
+def test_batched_queries_share_one_pass_over_the_byte_mirror(built, k):
+    """mi_knn_search with nq > 1 and mi_knn_search_batched_device used to bypass the prefilter.  With the
+    byte mirror 8 (or 4) queries now share ONE stage-1 pass (knn_scan_coarse8_batched_kernel: a query per 16-lane group,
+    rows handed round by ds_bpermute), each followed by its own stage 2: ids and distance bits of nq single searches."""
+    import torch
+    t = EmbeddingTable(DIM, 0)
+    t.insert_synthetic(31, 0, N + 1234)                         # a ragged last tile
+    rng = np.random.default_rng(100 + k)
+    qs = rng.standard_normal((13, DIM)).astype(np.float32)
+    qs[3] = t.rows(777, 1)[0]                                   # a stored row as a query
+    qs[9] = 0.0                                                 # a zero query: every distance NaN
+    want = t.knn(qs, k)                                         # prefilter off: the single pass (batched fp32 kernel for k <= 64)
+    t.set_option("prefilter", 2)
+    singles = [t.knn(q, k) for q in qs]                         # two-stage, one query at a time
+    for u in range(13):
+        assert np.array_equal(singles[u][0], want[0][u]) and np.array_equal(singles[u][1].view(np.uint32), want[1][u].view(np.uint32))
+    got = t.knn(qs, k)                                          # 13 = 8 + 4 + 1: two shared passes and a single search
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+    cand, fell_back = t.prefilter_stats()
+    assert not fell_back and cand >= min(k, 1)
+    d_q = torch.from_numpy(qs).cuda()
+    d_i = torch.empty((13, k), dtype=torch.int64, device="cuda")
+    d_d = torch.empty((13, k), dtype=torch.float32, device="cuda")
+    for nq in (4, 8, 12, 13):
+        d_i.zero_(); d_d.zero_()
+        t.knn_device(d_q.data_ptr(), nq, k, d_i.data_ptr(), d_d.data_ptr(), torch.cuda.current_stream().cuda_stream, batched=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_i.cpu().numpy()[:nq].view(np.uint64), want[0][:nq])
+        assert np.array_equal(d_d.cpu().numpy()[:nq].view(np.uint32), want[1][:nq].view(np.uint32))
+    t.close()

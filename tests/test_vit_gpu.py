@@ -352,6 +352,37 @@ def test_text_tower_bf16_within_the_bf16_bound_and_causal(built, tmp_path, name,
     m.close()
 
 
+def test_one_text_query_takes_the_skinny_gemm_path_within_the_same_bound(built, tmp_path):
+    """server/src/clip.rs:19-23 embeds ONE query per search: n == 1 on the CLIP-L text geometry runs on the skinny GEMMs
+    (vit.hip forward_text_one: every workgroup one K chunk, all loads in flight at once).  Same graph, same bf16 rounding
+    points (fc2's output stays fp32): each row must meet the bf16 bound against the transformers golden on its own, agree
+    with the batched kernels far inside that bound, and keep the causal mask."""
+    from image_search_amd.clip import PRECISION_BF16 as BF16
+    cfg = synth.TextConfig.clip_l14()
+    g = np.load(os.path.join(GOLDEN, "text_l14.npz"))
+    w = synth.vit_weights(cfg, int(g["seed"]))
+    path = str(tmp_path / "text.safetensors")
+    synth.save_safetensors(w, path, {"num_attention_heads": cfg.heads})
+    ids = synth.token_ids(cfg, int(g["ids_seed"]), int(g["n_seq"]))
+    m = TextModel.from_file(path, 0, BF16)
+    batched = m.embed(ids)                                         # n > 1: the batched kernels
+    rms = float(np.sqrt((np.asarray(g["embeds_f64"], np.float64) ** 2).mean()))
+    for i in range(ids.shape[0]):
+        one = m.embed(ids[i:i + 1])                                # n == 1: the skinny path
+        err = float(np.abs(one[0] - g["embeds_f64"][i]).max() / rms)
+        assert err <= 3e-2, (i, err)
+        assert float(np.abs(one[0] - batched[i]).max() / rms) <= 2e-2
+        m.set_option("text_fast", 0)
+        assert np.array_equal(m.embed(ids[i:i + 1])[0], batched[i])   # the same query through the batched kernels: their bits
+        m.set_option("text_fast", 1)
+        cut = ids[i:i + 1].copy()
+        cut[0, int(cut[0].argmax()) + 1:] = 0                      # tokens behind the EOS cannot reach the pooled row
+        assert np.array_equal(m.embed(cut), one)
+        assert np.array_equal(m.embed(ids[i:i + 1]), one)          # deterministic: fixed summation orders throughout
+        print(f"text query {i}, skinny path: max|err|/rms = {err:.2e}")
+    m.close()
+
+
 def test_text_tower_errors_are_codes(built, tmp_path):
     cfg = synth.TextConfig.tiny()
     path = str(tmp_path / "text.safetensors")

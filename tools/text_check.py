@@ -22,6 +22,14 @@ for pname, prec in (("fp32", PRECISION_F32), ("bf16", PRECISION_BF16)):
         print(f"{pname} n={n}: {dt*1e3:.3f} ms per call (host pointers in and out) = {n/dt:.0f} queries/s")
     if prec == PRECISION_BF16:
         m16 = m
+        ids = synth.token_ids(cfg, 11, 1)
+        for fast in (0, 1):
+            m.set_option("text_fast", fast)
+            m.embed(ids)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                m.embed(ids)
+            print(f"bf16 n=1 text_fast={fast}: {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms per call")
     else:
         m.close()
 m = TextModel.from_file(path)
