@@ -788,12 +788,13 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_kernel(const uint8_t*
 }
 
 // stage 1 on the byte mirror for NQ = 4 or 8 queries in ONE pass over the mirror (the throughput form of the two-stage
-// search).  The loads are those of knn_scan_coarse8_kernel — the four 16-lane groups of a wave fetch four different rows
-// per instruction — but each GROUP keeps its own query (NQ = 8: two): a fetched row is handed round the groups by
-// ds_bpermute (12 dwords per lane and row at dim 768, cheap beside the 48 byte conversions), so every group meets every
-// row with its own query.  Per (row, query) the arithmetic is knn_scan_coarse8_kernel's, operation for operation: the
-// same four fmaf chains, pairwise sum and butterfly, hence the same upper-bound keys and the same candidates as NQ single
-// searches.  all_keys: [NQ][key_stride], rho_out: [NQ].
+// search).  Each 16-lane GROUP of a wave keeps its own query (NQ = 8: two) and all four groups read the SAME row — the
+// addresses coincide, so the row crosses the memory system once — eight rows ahead.  (Handing rows fetched by different
+// groups round with ds_bpermute, the first form, was bound by the CU's one LDS pipe: 9.2 ms per 8 queries over 10 M rows.)
+// With the bytes shared, the pass is bound by the vector ALU: 48 byte conversions per row for all queries together plus
+// 48 fused multiply-adds per row and query, issued as packed pairs (v_pk_fma_f32).  Per (row, query) the arithmetic is
+// knn_scan_coarse8_kernel's, operation for operation — four fmaf chains, pairwise sum, butterfly — hence the same
+// upper-bound keys and the same candidates as NQ single searches.  all_keys: [NQ][key_stride], rho_out: [NQ].
 template <int NCH, int NQ>
 __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_batched_kernel(const uint8_t* __restrict__ mirror, const float* __restrict__ xx,
                                                                         const float* __restrict__ scale, const float* __restrict__ cfac,
@@ -802,11 +803,12 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_batched_kernel(const 
                                                                         uint32_t* __restrict__ all_keys, uint64_t key_stride,
                                                                         float* __restrict__ rho_out) {
     static_assert(NCH % 4 == 0 && (NQ == 4 || NQ == 8), "whole 256-byte chunks; one or two queries per 16-lane group");
-    constexpr int DIM = NCH * 64, U = NCH / 4, QPG = NQ / 4;
+    constexpr int DIM = NCH * 64, U = NCH / 4, QPG = NQ / 4, AHEAD = NQ == 8 ? 4 : 8;  // rows in flight: what the register file leaves beside the queries
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
     const uint32_t wave = blockIdx.x * 4 + wib, n_waves = gridDim.x * 4;
-    float qf[QPG][U][16];
+    f32x2 qf[QPG][U][8];  // pairs (e, e + 1) of the 16 query elements of a 16-byte piece
     float sq[QPG], rho[QPG], qsum128[QPG];
 #pragma unroll
     for (int c = 0; c < QPG; ++c) {
@@ -818,9 +820,10 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_batched_kernel(const 
             for (int e = 0; e < 16; ++e) {
                 const float qe = qq[256 * u + 16 * i + e];
                 s2 = __builtin_fmaf(qe, qe, s2);
-                qf[c][u][e] = qe * gch[256 * u + 16 * i + e];
-                s1 += fabsf(qf[c][u][e]);
-                ss += qf[c][u][e];
+                const float qg = qe * gch[256 * u + 16 * i + e];
+                qf[c][u][e >> 1][e & 1] = qg;
+                s1 += fabsf(qg);
+                ss += qg;
             }
         sq[c] = sqrtf(row16_sum(s2));
         rho[c] = row16_sum(s1) / sq[c] * 1.000001f;
@@ -830,56 +833,58 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_batched_kernel(const 
     const uint64_t n_tiles = (n_rows + 63) >> 6;
     auto load_row = [&](u32x4 (&x)[U], uint64_t r) {
         r = r < n_rows ? r : n_rows - 1;
-        const u32x4* p = reinterpret_cast<const u32x4*>(mirror + r * DIM) + i;
+        const u32x4* p = reinterpret_cast<const u32x4*>(mirror + r * DIM) + i;  // the same 16 lanes' worth of addresses in all four groups
 #pragma unroll
         for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(p + 16 * u);
     };
     for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
-        float mydot[QPG][4];  // [query of this group][source group sg]: lane i keeps row 16 sg + i of the tile
-        const uint64_t row0 = (tile << 6) + 16 * g;
-        u32x4 xr[4][U];
+        const uint64_t row0 = tile << 6;
+        u32x4 xr[AHEAD][U];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) load_row(xr[d], row0 + d);
+        for (int d = 0; d < AHEAD; ++d) load_row(xr[d], row0 + d);
+        float mydot[QPG];
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            if (it + 3 < 16) load_row(xr[(it + 3) & 3], row0 + it + 3);
-            const u32x4(&own)[U] = xr[it & 3];
+        for (int c = 0; c < QPG; ++c) mydot[c] = 0.0f;
+#pragma unroll 1
+        for (int s0 = 0; s0 < 64; s0 += AHEAD) {  // AHEAD rows per trip: the ring slot of a row is a compile-time index
 #pragma unroll
-            for (int sg = 0; sg < 4; ++sg) {  // the row group sg fetched in this step: tile row 16 sg + it
-                uint32_t w[U][4];
+            for (int e = 0; e < AHEAD; ++e) {
+                const int it = s0 + e;  // row of the tile; lane i keeps the dots of rows 16 s + i
+                u32x4(&x)[U] = xr[e];
+                f32x2 a01[QPG], a23[QPG];
+#pragma unroll
+                for (int c = 0; c < QPG; ++c) { a01[c] = (f32x2){0.0f, 0.0f}; a23[c] = (f32x2){0.0f, 0.0f}; }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const uint32_t o[4] = {own[u].x, own[u].y, own[u].z, own[u].w};
+                    const uint32_t w[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w[u][j] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (16 * sg + i), (int)o[j]);
+                    for (int j = 0; j < 4; ++j) {  // v_cvt_f32_ubyte0..3 once per row, shared by the group's queries
+                        const f32x2 b01 = (f32x2){(float)(w[j] & 0xFFu), (float)((w[j] >> 8) & 0xFFu)};
+                        const f32x2 b23 = (f32x2){(float)((w[j] >> 16) & 0xFFu), (float)(w[j] >> 24)};
+#pragma unroll
+                        for (int c = 0; c < QPG; ++c) {
+                            a01[c] = __builtin_elementwise_fma(qf[c][u][2 * j], b01, a01[c]);      // chains a[0], a[1]
+                            a23[c] = __builtin_elementwise_fma(qf[c][u][2 * j + 1], b23, a23[c]);  // chains a[2], a[3]
+                        }
+                    }
                 }
+                if (it + AHEAD < 64) load_row(x, row0 + it + AHEAD);  // the slot just used takes the row AHEAD further on
 #pragma unroll
                 for (int c = 0; c < QPG; ++c) {
-                    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            a[0] = __builtin_fmaf(qf[c][u][4 * j + 0], (float)(w[u][j] & 0xFFu), a[0]);
-                            a[1] = __builtin_fmaf(qf[c][u][4 * j + 1], (float)((w[u][j] >> 8) & 0xFFu), a[1]);
-                            a[2] = __builtin_fmaf(qf[c][u][4 * j + 2], (float)((w[u][j] >> 16) & 0xFFu), a[2]);
-                            a[3] = __builtin_fmaf(qf[c][u][4 * j + 3], (float)(w[u][j] >> 24), a[3]);
-                        }
-                    const float d = row16_sum((a[0] + a[1]) + (a[2] + a[3]));
-                    if (i == it) mydot[c][sg] = d;
+                    const float d = row16_sum((a01[c].x + a01[c].y) + (a23[c].x + a23[c].y));
+                    if (i == (it & 15)) mydot[c] = d;
                 }
             }
-        }
+            if (((s0 + AHEAD) & 15) == 0) {  // sixteen rows done: lane i holds row 16 s + i of its queries
+                const uint64_t r = row0 + (uint64_t)(s0 + AHEAD - 16) + i;
+                if (r < n_rows) {
+                    const float s = xx[r], sc = scale[r], cf = cfac[r];
 #pragma unroll
-        for (int sg = 0; sg < 4; ++sg) {
-            const uint64_t r = (tile << 6) + 16 * sg + i;
-            if (r < n_rows) {
-                const float s = xx[r], sc = scale[r], cf = cfac[r];
-#pragma unroll
-                for (int c = 0; c < QPG; ++c) {
-                    const float dot = sc * (mydot[c][sg] - qsum128[c]);
-                    const float upper = (1.0f - dot / (sq[c] * sqrtf(s))) + (cf * rho[c] + e0);
-                    all_keys[(size_t)(g + 4 * c) * key_stride + r] = s < 0.0f ? PREF_MARK : dist_to_u32(upper);
+                    for (int c = 0; c < QPG; ++c) {
+                        const float dot = sc * (mydot[c] - qsum128[c]);
+                        const float upper = (1.0f - dot / (sq[c] * sqrtf(s))) + (cf * rho[c] + e0);
+                        all_keys[(size_t)(g + 4 * c) * key_stride + r] = s < 0.0f ? PREF_MARK : dist_to_u32(upper);
+                    }
                 }
             }
         }
