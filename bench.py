@@ -79,6 +79,8 @@ def parse_args(argv=None):
     ap.add_argument("--prefilter", type=int, default=2, choices=(1, 2), help="mirror of the two-stage exact search: 2 = bytes (default), 1 = bf16")
     ap.add_argument("--backend", default="auto", help="torch.distributed backend: nccl (== RCCL), gloo, or auto = nccl when every rank has "
                                                       "its own GPU, gloo when ranks share one (rehearsals)")
+    ap.add_argument("--sharded-probe", action="store_true", help="(internal) the ONE-process form over every visible GPU — mi_knn_sharded + "
+                    "mi_pipeline_create_sharded — as a child of the N = 1 run; prints one JSON object")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: launch, rendezvous, the exchange + merge over fake per-rank lists "
                                                           "(what the CPU test of the self-launch path runs)")
     return ap.parse_args(argv)
@@ -204,6 +206,98 @@ def cpu_baseline(weights, cfg):
     return out
 
 
+def sharded_probe(args) -> int:
+    """BASELINE config 5 as the reference's ONE server process would run it (server/src/main.rs:30-35): one table over every
+    visible GPU (on a one-GPU box: two shards on GPU 0), a tower replica per shard, ingest + query through
+    mi_pipeline_create_sharded.  Small on purpose (it rides along with the N = 1 bench): rows_per_shard rows per shard."""
+    import torch
+
+    from image_search_amd import synth
+    from image_search_amd.clip import PRECISION_BF16, Model
+    from image_search_amd.search import EmbeddingTable, PinnedBuffer, Pipeline, ShardedTable
+
+    n_dev = torch.cuda.device_count()
+    devices = list(range(n_dev)) if n_dev > 1 else [0, 0]
+    n = len(devices)
+    rows_per_shard, batch = 1_000_000, args.batch
+    cfg = synth.VitConfig.vit_l14()
+    wpath = os.path.join(tempfile.gettempdir(), "mi355clip_bench_vitl14_seed0.safetensors")
+    out = {"devices": devices, "shards": n}
+    # 1. the search: small table against one mi_knn (bit equality), then rows_per_shard per shard (timing)
+    small = ShardedTable(768, devices, 256)
+    small.insert_synthetic(5, 0, 200_000)
+    one = EmbeddingTable(768, devices[0])
+    one.insert_synthetic(5, 0, 200_000)
+    qs = synth.corpus_rows(6, 0, 8)
+    eq = True
+    for k in (10, 1000):
+        a, b = small.knn(qs, k), one.knn(qs, k)
+        eq = eq and bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)))
+    out["transport"] = small.info()["transport"]
+    out["equal_to_one_table"] = eq
+    small.close(); one.close()
+    big = ShardedTable(768, devices, batch)
+    big.reserve(n * rows_per_shard + 64 * batch * n)
+    big.insert_synthetic(0, 0, n * rows_per_shard)
+    for mode in (0, 2):
+        big.set_option("prefilter", mode)
+        for u in range(3):
+            big.knn(qs[u], args.k)
+        t0 = time.perf_counter()
+        pend = [big.knn_async(qs[u % 8], args.k) for u in range(24)]
+        big.sync()
+        ms = (time.perf_counter() - t0) / 24 * 1e3
+        out["knn_ms_per_query" + ("_two_stage" if mode else "")] = round(ms, 4)
+    out["rows"] = len(big)
+    # 2. scan task + search handler in the one process: a replica per shard, chunks of n x batch images
+    models = [Model.from_file(wpath, d, PRECISION_BF16) for d in (devices if n_dev > 1 else devices[:1])]
+    if n_dev <= 1:
+        models = models * n
+    pipe = Pipeline(models, big)
+    pins = [PinnedBuffer((n * batch, 3, cfg.image, cfg.image)) for _ in range(2)]
+    img = synth.preprocess_rgb8(synth.images_u8(77, batch, cfg.image))
+    for pb in pins:
+        for j in range(n):
+            pb.array[j * batch:(j + 1) * batch] = img
+    steps = 4
+    for i in range(2):
+        pipe.ingest(pins[i & 1].array); pipe.query(qs[0], args.k)
+    pipe.sync()
+    t0 = time.perf_counter()
+    res = []
+    for i in range(steps):
+        pipe.ingest(pins[i & 1].array)
+        res.append(pipe.query(qs[i % 8], args.k))
+    pipe.sync()
+    dt = time.perf_counter() - t0
+    out["pipeline_images_per_sec"] = round(steps * n * batch / dt, 1)
+    out["pipeline_ms_per_step"] = round(dt / steps * 1e3, 3)
+    out["pipeline_images_per_step"] = n * batch
+    out["rows_after"] = len(big)
+    out["shard_rows"] = [big.shard_rows(sidx) for sidx in range(n)]
+    pipe.close()
+    for m in set(models):
+        m.close()
+    big.close()
+    for pb in pins:
+        pb.close()
+    print("SHARDED_PROBE " + json.dumps(out), flush=True)
+    return 0
+
+
+def run_sharded_probe(args):
+    """the probe as a CHILD with its own deadline: a hang in a multi-GPU runtime call must not take the N = 1 line with it"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--sharded-probe", "--batch", str(args.batch), "--k", str(args.k)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after 240 s"}
+    for ln in r.stdout.splitlines():
+        if ln.startswith("SHARDED_PROBE "):
+            return json.loads(ln[len("SHARDED_PROBE "):])
+    return {"error": f"rc {r.returncode}: {r.stderr.strip().splitlines()[-1] if r.stderr.strip() else 'no output'}"}
+
+
 def dry_run(args, world, rank):
     """--dry-run: everything of the N-rank path that needs no GPU — launch, rendezvous, the packed all-gather and the
     merge through the C ABI — over fake per-rank lists whose merged answer is known."""
@@ -250,6 +344,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     if args.dry_run:
         return dry_run(args, world, rank)
+    if args.sharded_probe:
+        return sharded_probe(args)
 
     import torch
     import torch.distributed as dist
@@ -564,6 +660,10 @@ def main():
                                     and exchange_check["queries_merged"] == args.steps)
         if extra:
             out["other_configs"] = extra
+        if world == 1 and not args.no_extra_configs:
+            # the ONE-process form (mi_knn_sharded + mi_pipeline_create_sharded) over every GPU this process can see, as a
+            # child with its own deadline; on a one-GPU box: two shards and two replicas on GPU 0
+            out.setdefault("other_configs", {})["one_process_sharded"] = run_sharded_probe(args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(weights, cfg)
         failed = failed or two_stage_equal is False

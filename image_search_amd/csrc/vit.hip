@@ -1064,6 +1064,22 @@ int mi_op_attention(int device, int precision, const float* qkv, float* ctx, siz
     });
 }
 
+int mi_op_clock_probe(int device, void* stream, float* mhz) {
+    return guarded([&] {
+        if (!mhz) fail(MI_ERR_INVALID, "null argument");
+        DeviceGuard g(device);
+        unsigned long long* d = nullptr;
+        HIP_CHECK(hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d);
+        unsigned long long h[4] = {0, 0, 0, 0};
+        const hipError_t e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream);
+        const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize((hipStream_t)stream) : e;
+        (void)hipFree(d);
+        HIP_CHECK(e2);
+        *mhz = h[1] ? (float)((double)h[0] / (double)h[1] * 100.0) : 0.0f;  // shader cycles per 100 MHz reference tick
+    });
+}
+
 int mi_op_layernorm(int device, int precision, const float* x, const float* w, const float* b, float* y, size_t rows,
                     int d, float eps) {
     return guarded([&] {

@@ -313,6 +313,23 @@ __global__ void scatter_rows_kernel(const T* __restrict__ src, T* __restrict__ d
     }
 }
 
+// ------------------------------------------------------------------ diagnostic: the shader clock right now
+// MI355X_MICROARCH.md (6): in-kernel clock = delta s_memtime (shader cycles) / delta s_memrealtime (100 MHz) x 100 MHz,
+// around a fixed dependent-FMA loop (~0.1 ms).  out = {shader cycles, reference ticks, fma result (keeps the loop alive)}
+__global__ void clock_probe_kernel(unsigned long long* __restrict__ out) {
+    float x = (float)threadIdx.x * 1e-3f;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int i = 0; i < 40000; ++i) x = __builtin_fmaf(x, 0.999f, 1e-3f);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0; out[1] = r1 - r0;
+        out[2] = (unsigned long long)__float_as_uint(x);
+    }
+}
+
 // ------------------------------------------------------------------ one text query: skinny GEMMs
 // A text query is 77 token rows (server/src/clip.rs:19-23 sits in front of every search).  On those shapes a tiled GEMM
 // is a latency chain: three to a dozen workgroups, each walking K in steps that pay an HBM round trip apiece (~10 us

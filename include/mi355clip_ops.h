@@ -35,6 +35,12 @@ int mi_op_attention(int device, int precision, const float* qkv, float* ctx, siz
 int mi_op_layernorm(int device, int precision, const float* x, const float* w, const float* b, float* y,
                     size_t rows, int d, float eps);
 
+/* Diagnostic: the shader clock at this moment of `stream` (a hipStream_t; NULL = the null stream).  One wave runs a
+ * fixed dependent-FMA loop (~0.1 ms) between two readings of the shader-cycle counter (s_memtime) and of the 100 MHz
+ * reference counter (s_memrealtime); the call waits for it and returns *mhz = shader cycles / reference time.  Enqueued
+ * behind a forward on the same stream it reads the clock the chip holds under that load. */
+int mi_op_clock_probe(int device, void* stream, float* mhz);
+
 #ifdef __cplusplus
 }
 #endif
