@@ -326,7 +326,7 @@ void layer_norm(mi_clip* m, float* x, const bf16_t* d1, const bf16_t* d2, bool w
     if (m->precision == MI_PRECISION_F32) {
         MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<float, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (float*)y, w, b, (int)rows, m->eps, y_ld, 0));
     } else if (write_back) {
-        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, y_ld, split));
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, y_ld, split, m->ln_nt ? 1 : 0));
     } else {
         MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, false>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, y_ld, split));
     }
@@ -764,6 +764,7 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         if (const char* e = std::getenv("MI_CLIP_ATTN")) m->attn_ver = std::atoi(e) == 1 ? 1 : 2;  // fixed at load: decides the q scale
         if (const char* e = std::getenv("MI_GEMM_SPLIT")) m->split_tail = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_CLIP_IM2COL")) m->im2col_rows = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MI_CLIP_LN_NT")) m->ln_nt = std::atoi(e) != 0;
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         m->n_cu = prop.multiProcessorCount;

@@ -238,6 +238,13 @@ struct LnRow {
 #pragma unroll
         for (int t = 0; t < NT; ++t) st_vec<VEC, T>(p + (t * 64 + lane) * VEC, &v[t * VEC]);
     }
+    // fp32 row with the non-temporal hint: the residual stream is not read again before the next LayerNorm
+    __device__ __forceinline__ void store_nt(float* __restrict__ p, int lane) const {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) __builtin_nontemporal_store(v[t * VEC + c], p + (t * 64 + lane) * VEC + c);
+    }
 };
 
 // y[row] = LN(x[row] + d1[row] + d2[row]) for row < rows; 4 rows per 256-thread block (bf16 path:
@@ -249,10 +256,10 @@ struct LnRow {
 //   the normalised value that bf16 rounding dropped, lo = bf16(v - float(bf16(v))): the GEMM that follows runs
 //   over K = 2D against [W | W] and sees the activations to ~16 significant bits.
 template <typename T, int VEC, int NT, bool WRITE_BACK>
-__global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const bf16_t* __restrict__ d1,
+__device__ __forceinline__ void ln_body(float* __restrict__ x, const bf16_t* __restrict__ d1,
                                                  const bf16_t* __restrict__ d2, T* __restrict__ y,
                                                  const float* __restrict__ w, const float* __restrict__ b, int rows,
-                                                 float eps, int y_ld, int split) {
+                                                 float eps, int y_ld, int split, int nt_x) {
     constexpr int D = 64 * VEC * NT;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -261,7 +268,10 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const bf
     r.load(x + (size_t)row * D, lane);
     if (d1) r.add_bf16(d1 + (size_t)row * D, lane);
     if (d2) r.add_bf16(d2 + (size_t)row * D, lane);
-    if (WRITE_BACK && (d1 || d2)) r.store(x + (size_t)row * D, lane);
+    if (WRITE_BACK && (d1 || d2)) {
+        if (nt_x) r.store_nt(x + (size_t)row * D, lane);
+        else r.store(x + (size_t)row * D, lane);
+    }
     r.normalize(w, b, eps, lane);
     r.store(y + (size_t)row * y_ld, lane);
     if constexpr (sizeof(T) == 2) {
@@ -273,6 +283,13 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const bf
     }
 }
 
+template <typename T, int VEC, int NT, bool WRITE_BACK>
+__global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const bf16_t* __restrict__ d1,
+                                                 const bf16_t* __restrict__ d2, T* __restrict__ y,
+                                                 const float* __restrict__ w, const float* __restrict__ b, int rows,
+                                                 float eps, int y_ld, int split, int nt_x = 0) {
+    ln_body<T, VEC, NT, WRITE_BACK>(x, d1, d2, y, w, b, rows, eps, y_ld, split, nt_x);
+}
 // token assembly + pre-LN (modeling_clip.py:198-218, :641-651):
 // x[b*S+s] = LN_pre((s == 0 ? cls : patch[b*(S-1)+s-1]) + pos[s])
 template <int VEC, int NT>

@@ -60,6 +60,29 @@ for kind in ("iid", "heavy tails", "outlier channels", "clusters", "unit norm, s
              "candidates_median": int(np.median(cands)), "candidates_max": int(max(cands))}
         print(r, file=sys.stderr, flush=True)
         out["results"].append(r)
+    # the batched form (round 3): 8 and 4 queries share one pass over the byte mirror; near-a-stored-row and random queries
+    # mixed in one call, every k; must equal the single pass query by query
+    t.set_option("prefilter", 0)
+    mism = 0; calls = 0
+    for j in range(max(4, QUERIES // 4)):
+        k = (1, 10, 100, 1000)[j % 4]
+        nq = (8, 4, 13, 16)[j % 4]
+        qs = torch.randn((nq, 768), device="cuda", generator=gen)
+        near = torch.randint(0, N, (nq,), device="cuda", generator=gen)
+        pick = torch.arange(nq, device="cuda") % 3 == 0
+        qs[pick] = x[near[pick]] + 0.02 * qs[pick]
+        qh = qs.cpu().numpy()
+        t.set_option("prefilter", 0)
+        a = t.knn(qh, k)
+        t.set_option("prefilter", 2)
+        b = t.knn(qh, k)
+        calls += 1
+        if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))):
+            mism += 1
+    ok &= mism == 0
+    r = {"corpus": kind, "mirror": "bytes, batched calls of 8 / 4 / 13 / 16 queries", "calls": calls, "mismatches": mism}
+    print(r, file=sys.stderr, flush=True)
+    out["results"].append(r)
     t.close()
     del x
 print(json.dumps(out, indent=1))
