@@ -169,7 +169,7 @@ struct PinnedBuf2 {
         if (b <= cap) return;
         if (p) HIP_CHECK(hipHostFree(p));
         p = nullptr; cap = 0;
-        HIP_CHECK(hipHostMalloc(&p, b, hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc(&p, b, hipHostMallocPortable));  // read and written by streams of several devices
         cap = b;
     }
 };

@@ -443,7 +443,8 @@ int mi_host_alloc(size_t bytes, void** out) {
         *out = nullptr;
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) fail(MI_ERR_NO_DEVICE, "no HIP device visible: pinned memory needs the runtime");
-        HIP_CHECK(hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault));
+        // portable: a chunk in this memory is uploaded to several GPUs by a sharded pipeline
+        HIP_CHECK(hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocPortable));
     });
 }
 
