@@ -170,3 +170,24 @@ def test_resize_oracle_properties(orc):
     big = synth.photo_u8(6, 333, 500)
     assert np.array_equal(orc_image_prepare_resnet(orc, big),
                           synth.preprocess_rgb8(orc_resize_catmullrom(orc, big, 224, 224)[None])[0])
+
+
+def test_torch_cpu_baseline_is_the_same_graph_as_the_numpy_port():
+    """oracle/vit_torch.py (bench.py's "library" CPU baseline: torch's own GEMMs, fused attention, topk) against the
+    numpy restatement on the tiny config: the same function up to summation order; its kNN returns the port's ids."""
+    import torch
+    from oracle import vit_numpy, vit_torch
+    from oracle.binding import load_oracle, orc_knn
+    cfg = synth.VitConfig.tiny()
+    w = synth.vit_weights(cfg, 4)
+    px = synth.preprocess_rgb8(synth.images_u8(9, 3, cfg.image))
+    a = vit_numpy.vit_forward(w, cfg, px, np.float32)
+    b = vit_torch.vit_forward(vit_torch.load_weights(w), cfg, px).numpy()
+    assert np.abs(a - b).max() <= 1e-4 * np.sqrt((a ** 2).mean())
+    rows = synth.corpus_rows(3, 0, 5000)
+    q = synth.corpus_rows(4, 0, 1)[0]
+    tr = torch.from_numpy(rows)
+    ti, td = vit_torch.knn(tr, tr.norm(dim=1), torch.from_numpy(q), 10)
+    oi, od = orc_knn(load_oracle(), q, rows, 10)
+    assert np.array_equal(ti.numpy().astype(np.uint64), oi)
+    assert np.abs(td.numpy() - od).max() < 1e-5
