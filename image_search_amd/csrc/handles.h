@@ -106,6 +106,7 @@ struct mi_knn {
     // two-stage exact search (mi_knn_set_option "prefilter"): a bf16 copy of the rows + their squared norms, kept up to
     // `mirror_rows` and caught up by the next search; candidate rows / keys of stage 2
     int prefilter = 0;              // 0 off, 1 bf16 mirror, 2 byte mirror
+    int coarse_ring = 8;            // rows in flight + 1 per lane group in the byte stage-1 scan (MI_KNN_RING: A/B)
     bool last_prefiltered = false;  // the most recent single-query search went through the two stages
     uint16_t* d_mirror = nullptr;   // bf16 rows (prefilter 1) or byte rows (prefilter 2: dim bytes per row)
     float* d_scale8 = nullptr;      // prefilter 2: per-row scale, per-row bound factor, rho of the query in flight

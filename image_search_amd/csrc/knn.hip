@@ -163,6 +163,9 @@ void launch_coarse8_batched(mi_knn* t, const uint8_t* m8, const float* d_q, floa
         if (nq == 8)
             hipLaunchKernelGGL((knn_scan_coarse8_batched_kernel<NCH, 8>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8, t->d_cfac8,
                                t->d_g8, t->rows, d_q, e0, t->d_keys32, (uint64_t)t->cap, t->d_rho8);
+        else if (nq == 2)
+            hipLaunchKernelGGL((knn_scan_coarse8_batched_kernel<NCH, 2>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8, t->d_cfac8,
+                               t->d_g8, t->rows, d_q, e0, t->d_keys32, (uint64_t)t->cap, t->d_rho8);
         else
             hipLaunchKernelGGL((knn_scan_coarse8_batched_kernel<NCH, 4>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8, t->d_cfac8,
                                t->d_g8, t->rows, d_q, e0, t->d_keys32, (uint64_t)t->cap, t->d_rho8);
@@ -212,6 +215,7 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s,
     const size_t sel_bytes = ((size_t)6 * SEL_BINS + 64) * sizeof(uint32_t);
     HIP_CHECK(hipMemsetAsync(t->d_sel, 0, sel_bytes, s));
     HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), s));
+    static const uint32_t ring8_bpc = [] { const char* e = std::getenv("MI_KNN_RING_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 2u; }();  // A/B
     const float e0 = 4.1f * (float)(t->dim + 8) * 0x1p-24f + 2e-6f;  // fp32 summations, norms, divisions
     const float eps = 0x1p-8f + e0;                                  // bf16: 8 significant bits, unit roundoff 2^-8
     if (bytes) {
@@ -227,8 +231,11 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s,
                                t->rows, t->d_g8, m8, t->d_xx, t->d_scale8, t->d_cfac8);                                  \
             t->mirror_rows = t->rows;                                                                                    \
         }                                                                                                                \
-        if (nq_batch == 0)                                                                                               \
-            hipLaunchKernelGGL((knn_scan_coarse8_kernel<NCH>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8,  \
+        if (nq_batch == 0 && t->coarse_ring == 8)  /* 169 VGPRs: two workgroups per CU are resident, launch exactly those */ \
+            hipLaunchKernelGGL((knn_scan_coarse8_kernel<NCH, 8>), dim3(std::min(blocks, (uint32_t)t->n_cu * ring8_bpc)), dim3(256), 0, s, m8, t->d_xx, t->d_scale8, \
+                               t->d_cfac8, t->d_g8, t->rows, d_q, e0, t->d_keys32, t->d_rho8);                           \
+        else if (nq_batch == 0)                                                                                          \
+            hipLaunchKernelGGL((knn_scan_coarse8_kernel<NCH, 4>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8, \
                                t->d_cfac8, t->d_g8, t->rows, d_q, e0, t->d_keys32, t->d_rho8);                           \
         else if (qi == 0)                                                                                                \
             launch_coarse8_batched<NCH>(t, m8, d_q, e0, nq_batch, blocks, s);                                            \
@@ -396,7 +403,7 @@ void two_stage_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, flo
     HIP_CHECK(hipGetLastError());
 }
 
-// nq = 4 or 8 queries (contiguous at d_q) through the two stages with ONE pass over the byte mirror; bit-identical to nq
+// nq = 2, 4 or 8 queries (contiguous at d_q) through the two stages with ONE pass over the byte mirror; bit-identical to nq
 // single searches (the per-(row, query) arithmetic of stage 1 is the single kernel's; stage 2 is the single search's own)
 bool batched_two_stage_applies(const mi_knn* t, uint32_t k) {
     return t->prefilter == 2 && t->dim == 768 && prefilter_applies(t, k) && !(t->pref_adaptive && (t->pref_skip_left || t->pref_probing));
@@ -537,6 +544,7 @@ int mi_knn_create(uint32_t dim, int device, mi_knn** out) {
         t->n_cu = prop.multiProcessorCount;
         HIP_CHECK(hipMalloc((void**)&t->d_q, (size_t)16 * dim * sizeof(float)));
         if (const char* e = std::getenv("MI_KNN_SELECT")) t->select_path = std::atoi(e) != 0;  // A/B hook, read at creation
+        if (const char* e = std::getenv("MI_KNN_RING")) t->coarse_ring = std::atoi(e) == 8 ? 8 : 4;
         *out = t;
     });
 }
@@ -843,8 +851,8 @@ int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint3
         uint32_t u = 0;
         while (u < nq) {
             const uint32_t left = nq - u;
-            if (left >= 4 && batched_two_stage_applies(t, k)) {  // one pass over the byte mirror serves 8 (or 4) queries
-                const uint32_t b2 = left >= 8 ? 8 : 4;
+            if (left >= 2 && batched_two_stage_applies(t, k)) {  // one pass over the byte mirror serves 8, 4 or 2 queries
+                const uint32_t b2 = left >= 8 ? 8 : left >= 4 ? 4 : 2;
                 search_batched_two_stage(t, d_q + (size_t)u * t->dim, b2, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
                 u += b2;
                 continue;
@@ -892,8 +900,8 @@ int mi_knn_search(mi_knn* t, const float* q, uint32_t nq, uint32_t k, uint64_t* 
             uint32_t u = 0;
             while (u < ng) {
                 const uint32_t left = ng - u;
-                if (left >= 4 && batched_two_stage_applies(t, k)) {
-                    const uint32_t b2 = left >= 8 ? 8 : 4;
+                if (left >= 2 && batched_two_stage_applies(t, k)) {
+                    const uint32_t b2 = left >= 8 ? 8 : left >= 4 ? 4 : 2;
                     search_batched_two_stage(t, t->d_q + (size_t)u * t->dim, b2, k, t->d_idx + (size_t)u * k, t->d_dist + (size_t)u * k, t->stream);
                     u += b2;
                     continue;

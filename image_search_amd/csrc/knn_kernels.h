@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void knn_mirror8_kernel(const float* __restric
 
 // stage 1 on the byte mirror: every row's UPPER-bound key (PREF_MARK for the marked rows).  Lane i of a 16-lane group
 // loads the 16 bytes at offset 256 u + 16 i of its row (dim a multiple of 256); rho_out[0] = rho for the collect pass.
-template <int NCH>
+template <int NCH, int RING = 4>
 __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_kernel(const uint8_t* __restrict__ mirror, const float* __restrict__ xx,
                                                                const float* __restrict__ scale, const float* __restrict__ cfac,
                                                                const float* __restrict__ gch, uint64_t n_rows,
@@ -769,13 +769,14 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_kernel(const uint8_t*
             const float d = row16_sum((a[0] + a[1]) + (a[2] + a[3]));
             if (i == it) mydot = d;
         };
-        u32x4 xr[4][U];
+        // RING - 1 rows of 768 bytes in flight per 16-lane group (A/B: MI_KNN_RING = 4 | 8 at table creation)
+        u32x4 xr[RING][U];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) load_row(xr[d], row0 + d);
+        for (int d = 0; d < RING - 1; ++d) load_row(xr[d], row0 + d);
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-            if (it + 3 < 16) load_row(xr[(it + 3) & 3], row0 + it + 3);
-            reduce_row(xr[it & 3], it);
+            if (it + RING - 1 < 16) load_row(xr[(it + RING - 1) % RING], row0 + it + RING - 1);
+            reduce_row(xr[it % RING], it);
         }
         const uint64_t r = (tile << 6) + lane;
         if (r < n_rows) {
@@ -802,17 +803,20 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_batched_kernel(const 
                                                                         const float* __restrict__ q, float e0,
                                                                         uint32_t* __restrict__ all_keys, uint64_t key_stride,
                                                                         float* __restrict__ rho_out) {
-    static_assert(NCH % 4 == 0 && (NQ == 4 || NQ == 8), "whole 256-byte chunks; one or two queries per 16-lane group");
-    constexpr int DIM = NCH * 64, U = NCH / 4, QPG = NQ / 4, AHEAD = NQ == 8 ? 4 : 8;  // rows in flight: what the register file leaves beside the queries
+    static_assert(NCH % 4 == 0 && (NQ == 2 || NQ == 4 || NQ == 8), "whole 256-byte chunks; 2, 4 or 8 queries");
+    // GQ lane groups hold different queries (QPG each); with NQ = 2 the other two groups take the NEXT row: RPS rows per step
+    constexpr int DIM = NCH * 64, U = NCH / 4, GQ = NQ < 4 ? NQ : 4, QPG = NQ / GQ, RPS = 4 / GQ, STEPS = 64 / RPS;
+    constexpr int AHEAD = NQ == 8 ? 4 : 8;  // rows in flight per group: what the register file leaves beside the queries
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
+    const int qg = g % GQ, rs = g / GQ;  // this group's query slot and its row within a step
     const uint32_t wave = blockIdx.x * 4 + wib, n_waves = gridDim.x * 4;
     f32x2 qf[QPG][U][8];  // pairs (e, e + 1) of the 16 query elements of a 16-byte piece
     float sq[QPG], rho[QPG], qsum128[QPG];
 #pragma unroll
     for (int c = 0; c < QPG; ++c) {
-        const float* qq = q + (size_t)(g + 4 * c) * DIM;  // group g: query g (and g + 4)
+        const float* qq = q + (size_t)(qg + GQ * c) * DIM;  // group: query qg (and qg + 4)
         float s2 = 0.0f, s1 = 0.0f, ss = 0.0f;
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -828,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_batched_kernel(const 
         sq[c] = sqrtf(row16_sum(s2));
         rho[c] = row16_sum(s1) / sq[c] * 1.000001f;
         qsum128[c] = 128.0f * row16_sum(ss);
-        if (blockIdx.x == 0 && wib == 0 && i == 0) rho_out[g + 4 * c] = rho[c];
+        if (blockIdx.x == 0 && wib == 0 && i == 0 && rs == 0) rho_out[qg + GQ * c] = rho[c];
     }
     const uint64_t n_tiles = (n_rows + 63) >> 6;
     auto load_row = [&](u32x4 (&x)[U], uint64_t r) {
@@ -841,15 +845,15 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_batched_kernel(const 
         const uint64_t row0 = tile << 6;
         u32x4 xr[AHEAD][U];
 #pragma unroll
-        for (int d = 0; d < AHEAD; ++d) load_row(xr[d], row0 + d);
+        for (int d = 0; d < AHEAD; ++d) load_row(xr[d], row0 + RPS * d + rs);
         float mydot[QPG];
 #pragma unroll
         for (int c = 0; c < QPG; ++c) mydot[c] = 0.0f;
 #pragma unroll 1
-        for (int s0 = 0; s0 < 64; s0 += AHEAD) {  // AHEAD rows per trip: the ring slot of a row is a compile-time index
+        for (int s0 = 0; s0 < STEPS; s0 += AHEAD) {  // AHEAD steps per trip: the ring slot of a row is a compile-time index
 #pragma unroll
             for (int e = 0; e < AHEAD; ++e) {
-                const int it = s0 + e;  // row of the tile; lane i keeps the dots of rows 16 s + i
+                const int it = s0 + e, row = RPS * it + rs;  // this group's row of the tile in this step
                 u32x4(&x)[U] = xr[e];
                 f32x2 a01[QPG], a23[QPG];
 #pragma unroll
@@ -868,22 +872,22 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_batched_kernel(const 
                         }
                     }
                 }
-                if (it + AHEAD < 64) load_row(x, row0 + it + AHEAD);  // the slot just used takes the row AHEAD further on
+                if (it + AHEAD < STEPS) load_row(x, row0 + RPS * (it + AHEAD) + rs);  // the slot just used takes the row AHEAD steps on
 #pragma unroll
                 for (int c = 0; c < QPG; ++c) {
                     const float d = row16_sum((a01[c].x + a01[c].y) + (a23[c].x + a23[c].y));
-                    if (i == (it & 15)) mydot[c] = d;
+                    if (i == (row & 15)) mydot[c] = d;
                 }
             }
-            if (((s0 + AHEAD) & 15) == 0) {  // sixteen rows done: lane i holds row 16 s + i of its queries
-                const uint64_t r = row0 + (uint64_t)(s0 + AHEAD - 16) + i;
-                if (r < n_rows) {
+            if (((RPS * (s0 + AHEAD)) & 15) == 0) {  // sixteen rows done: lane i (i % RPS == rs) holds row 16 s + i of its queries
+                const uint64_t r = row0 + (uint64_t)(RPS * (s0 + AHEAD) - 16) + i;
+                if (r < n_rows && (i % RPS) == rs) {
                     const float s = xx[r], sc = scale[r], cf = cfac[r];
 #pragma unroll
                     for (int c = 0; c < QPG; ++c) {
                         const float dot = sc * (mydot[c] - qsum128[c]);
                         const float upper = (1.0f - dot / (sq[c] * sqrtf(s))) + (cf * rho[c] + e0);
-                        all_keys[(size_t)(g + 4 * c) * key_stride + r] = s < 0.0f ? PREF_MARK : dist_to_u32(upper);
+                        all_keys[(size_t)(qg + GQ * c) * key_stride + r] = s < 0.0f ? PREF_MARK : dist_to_u32(upper);
                     }
                 }
             }

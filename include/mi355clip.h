@@ -225,8 +225,9 @@ int mi_knn_search(mi_knn* t, const float* q, uint32_t nq, uint32_t k, uint64_t* 
  * all-gather when the table is sharded. */
 int mi_knn_search_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx,
                          float* d_dist, void* stream);
-/* Throughput variant: ONE pass over the table serves all nq queries (nq <= 16);
- * results identical to nq calls of mi_knn_search_device with nq = 1. */
+/* Throughput variant: ONE pass over the table serves all nq queries (nq <= 16; passes of 8 / 4 / 2 queries — over the byte
+ * mirror when "prefilter" = 2 is on and dim is 768: one stage-1 pass for the group, a stage 2 per query; over the fp32
+ * rows otherwise, k <= 64); results identical to nq calls of mi_knn_search_device with nq = 1. */
 int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx,
                                  float* d_dist, void* stream);
 

@@ -419,7 +419,7 @@ def test_a_growing_table_keeps_its_mirror_and_refreshes_the_channel_scales_at_4x
 @pytest.mark.parametrize("k", [1, 10, 64, 1000])
 def test_batched_queries_share_one_pass_over_the_byte_mirror(built, k):
     """mi_knn_search with nq > 1 and mi_knn_search_batched_device used to bypass the prefilter.  With the
-    byte mirror 8 (or 4) queries now share ONE stage-1 pass (knn_scan_coarse8_batched_kernel: a query per 16-lane group,
+    byte mirror 8, 4 or 2 queries now share ONE stage-1 pass (knn_scan_coarse8_batched_kernel: a query per 16-lane group,
     rows handed round by ds_bpermute), each followed by its own stage 2: ids and distance bits of nq single searches."""
     import torch
     t = EmbeddingTable(DIM, 0)
@@ -440,7 +440,7 @@ def test_batched_queries_share_one_pass_over_the_byte_mirror(built, k):
     d_q = torch.from_numpy(qs).cuda()
     d_i = torch.empty((13, k), dtype=torch.int64, device="cuda")
     d_d = torch.empty((13, k), dtype=torch.float32, device="cuda")
-    for nq in (4, 8, 12, 13):
+    for nq in (2, 3, 4, 6, 7, 8, 12, 13):                       # shared passes of 8, 4 and 2 queries, single searches for the odd one
         d_i.zero_(); d_d.zero_()
         t.knn_device(d_q.data_ptr(), nq, k, d_i.data_ptr(), d_d.data_ptr(), torch.cuda.current_stream().cuda_stream, batched=True)
         torch.cuda.synchronize()

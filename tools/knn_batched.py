@@ -45,7 +45,7 @@ for k in (10, 1000):
     row["two_stage_single_ms_per_query"] = round(ms / 8, 4)
     row["two_stage_single_qps"] = round(8e3 / ms, 1)
     row["two_stage_single_equal"] = bool(np.array_equal(i_, ri) and np.array_equal(d_, rd))
-    for nq in (4, 8, 16):
+    for nq in (2, 4, 8, 16):
         ms, i_, d_ = run(nq, k, True, 10)
         row[f"two_stage_batched{nq}_ms_per_call"] = round(ms, 4)
         row[f"two_stage_batched{nq}_qps"] = round(nq * 1e3 / ms, 1)
