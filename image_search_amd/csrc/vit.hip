@@ -724,6 +724,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         else if (k == "split_tail") m->split_tail = value != 0;
         else if (k == "im2col_rows") m->im2col_rows = value != 0;
         else if (k == "text_fast") m->text_fast = value != 0;
+        else if (k == "ln_nt") m->ln_nt = value != 0;
         else if (k == "max_batch") {
             if (value < 1) fail(MI_ERR_INVALID, "max_batch must be >= 1");
             m->max_batch = (size_t)value;
@@ -737,7 +738,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, im2col_rows, text_fast, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, im2col_rows, ln_nt, text_fast, max_batch, parts)", key);
     });
 }
 

@@ -96,7 +96,10 @@ int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* nee
  *                the pooled output is the CLS row, the result is bit-identical either way)
  *   "attn_shift" 1 = always take the shifted (exact row maximum) pass of the bf16 attention (default 0: taken
  *                only for queries whose softmax numerators leave the exponent range; same result)
- *   "split_tail" 0 = do not cut a short last round of GEMM tiles into quadrant tasks (A/B hook) */
+ *   "split_tail" 0 = do not cut a short last round of GEMM tiles into quadrant tasks (A/B hook)
+ *   "im2col_rows" 0 = the patch gather in 4P-byte runs instead of the LDS-staged rows form (A/B hook; same bits)
+ *   "ln_nt"      1 = LN1 writes the residual stream back with the non-temporal hint (A/B hook; same bits)
+ *   "text_fast"  0 = a single text query takes the batched kernels instead of the skinny-GEMM path (text handles) */
 int mi_clip_set_option(mi_clip* m, const char* key, int value);
 
 /* geometry of a loaded model: out[0..7] = image, patch, tokens, hidden, layers,

@@ -420,6 +420,27 @@ def test_persistent_gemm_random_shapes_and_grids(built, monkeypatch):
         assert np.array_equal(got, ref), (case, grid, m, n, k)
 
 
+def test_ab_hooks_of_the_bf16_tower_do_not_change_a_bit(l14):
+    """im2col_rows (the LDS-staged patch gather) and ln_nt (non-temporal write-back of the residual stream) move bytes
+    differently, never compute differently: 40 images (two half-chunk streams), every combination, the same bits."""
+    cfg, w, path, u8, g = l14
+    px = synth.preprocess_rgb8(synth.images_u8(78, 40, cfg.image))
+    m = Model.from_file(path, 0, PRECISION_BF16)
+    ref = m.forward(px)
+    for rows_, nt in ((0, 0), (0, 1), (1, 1)):
+        m.set_option("im2col_rows", rows_)
+        m.set_option("ln_nt", nt)
+        assert np.array_equal(m.forward(px).view(np.uint32), ref.view(np.uint32)), (rows_, nt)
+    m.close()
+
+
+def test_clock_probe_reads_a_plausible_shader_clock(built):
+    from image_search_amd._lib import check, lib
+    v = ctypes.c_float()
+    check(lib().mi_op_clock_probe(0, None, ctypes.byref(v)))
+    assert 300.0 < v.value < 3500.0, v.value
+
+
 @pytest.mark.parametrize("prec", [PRECISION_F32, PRECISION_BF16])
 def test_cls_only_last_layer_is_bit_identical_to_the_full_one(l14, monkeypatch, prec):
     """Behind the last layer's attention only the CLS row is live; computing just that row must give
