@@ -380,6 +380,14 @@ def test_one_text_query_takes_the_skinny_gemm_path_within_the_same_bound(built, 
         assert np.array_equal(m.embed(cut), one)
         assert np.array_equal(m.embed(ids[i:i + 1]), one)          # deterministic: fixed summation orders throughout
         print(f"text query {i}, skinny path: max|err|/rms = {err:.2e}")
+    # the captured graph holds buffer addresses: a larger batch reallocates the workspace, the graph must go with it
+    first = m.embed(ids[:1])
+    for _ in range(3):
+        assert np.array_equal(m.embed(ids[:1]), first)             # eager, capturing, replayed
+    big = np.concatenate([ids] * 40)                               # grows the workspace (and takes the batched kernels)
+    assert np.array_equal(m.embed(big)[:ids.shape[0]], batched)
+    for _ in range(4):
+        assert np.array_equal(m.embed(ids[:1]), first)             # a fresh eager / capture / replay cycle on the new buffers
     m.close()
 
 
