@@ -943,8 +943,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
         const int h = (j >= 2) ? 1 : 0;
         unsigned char* dst = smem + buf * 65536 + (is_x ? 0 : 32768) + h * 16384 + wave * 2048;
         const uint32_t so = (is_x ? xs + x_wave + 64u * h * Kb : ws + w_wave + 32u * h * Kb) + (uint32_t)kt * 128u;
+#if defined(PP_ABL) && (PP_ABL & 1)  // probe builds only (tools/probe/gemm_bench.hip -DPP_ABL=mask): no operand DMA, LDS keeps what it holds
+        (void)so; (void)dst;
+#else
         glds16_buf(is_x ? xr : wr, x_lane, so, dst);
         glds16_buf(is_x ? xr : wr, x_lane, so + 8u * Kb, dst + 1024);
+#endif
     };
     unsigned char* bias_lds = smem + 131072 + 18432 + wave * 256;
     auto stage_bias = [&](int tn) {
@@ -1027,7 +1031,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
                 const int row = j * 8 + (lane >> 3);
                 const v4u d = *reinterpret_cast<const v4u*>(patch + row * 144 + (lane & 7) * 16);
                 const uint32_t so = o_tile + (uint32_t)(mi * 16 + j * 8) * (uint32_t)ldo * 2u;
+#if defined(PP_ABL) && (PP_ABL & 2)  // probe builds only: no output stores
+                asm volatile("" ::"v"(d), "v"(so));
+#else
                 __builtin_amdgcn_raw_buffer_store_b128(d, orr, o_lane, so, 0);
+#endif
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
