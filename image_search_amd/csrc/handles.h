@@ -56,6 +56,8 @@ struct mi_clip {
     size_t text_cap = 0;
     // one text query as a captured hipGraph (forward_text_one is ~90 short kernels; launched one by one the host's launch
     // calls cost more than the kernels): 0 = not yet run, 1 = ran once eagerly (function attributes are set), 2 = captured
+    int* h_ids_pin = nullptr;      // pinned staging of one query's ids / its embedding: the graph copies from / to them
+    float* h_out_pin = nullptr;
     int text_graph_state = 0;
     hipGraph_t text_graph = nullptr;
     hipGraphExec_t text_graph_exec = nullptr;
