@@ -132,25 +132,6 @@ class EmbeddingTable {
     void set_option(const std::string& key, int value) { check(mi_knn_set_option(h_, key.c_str(), value)); }
 };
 
-// the body of the scan loop and the query on HIP streams (BASELINE config 4; INTEGRATION.md section 2b)
-class Pipeline {
-    mi_pipeline* h_ = nullptr;
-
-   public:
-    Pipeline(clip_vit_large_patch14::Model& model, EmbeddingTable& table) { check(mi_pipeline_create(model.handle(), table.handle(), &h_)); }
-    Pipeline(const Pipeline&) = delete;
-    ~Pipeline() { mi_pipeline_free(h_); }
-    // [n,3,H,W] f32 (pinned memory from mi_host_alloc makes the upload asynchronous): returns the id of the first new row
-    uint64_t ingest(const float* nchw, size_t n) {
-        uint64_t first = 0;
-        check(mi_pipeline_ingest(h_, nchw, n, &first));
-        return first;
-    }
-    // results land in idx / dist when sync() (or drain) returns
-    void query(const float* q, uint32_t k, uint64_t* idx, float* dist) { check(mi_pipeline_query(h_, q, k, idx, dist)); }
-    void sync() { check(mi_pipeline_sync(h_)); }
-};
-
 // the whole table `image` {id, image_path, embedding} (server/src/search.rs:13-18) and the four statements the
 // server issues against it
 class ImageIndex {
@@ -231,6 +212,48 @@ class ShardedTable {
         check(mi_knn_sharded_search(h_, reference.data(), 1, k, idx.data(), dist.data()));
         return {idx, dist};
     }
+    // the same search without the wait: idx / dist (caller-owned, k entries each) are filled when sync() returns
+    void knn_async(const float* reference, uint32_t k, uint64_t* idx, float* dist) { check(mi_knn_sharded_search_async(h_, reference, 1, k, idx, dist)); }
+    void sync() { check(mi_knn_sharded_sync(h_)); }
+    // rows that are already in device memory on `src_device` (a replica's embeddings): routed to their shards device to device
+    uint64_t insert_device(const float* d_rows, uint64_t n, int src_device, void* stream = nullptr) {
+        uint64_t first = 0;
+        check(mi_knn_sharded_append_device(h_, d_rows, n, src_device, stream, &first));
+        return first;
+    }
+    // every row of `src` into this EMPTY table (another shard count / device set / block size), device to device
+    void rebalance_from(ShardedTable& src) { check(mi_knn_sharded_rebalance(h_, src.h_)); }
+    void save(const std::string& prefix) const { check(mi_knn_sharded_save(h_, prefix.c_str())); }
+    void load(const std::string& prefix) { check(mi_knn_sharded_load(h_, prefix.c_str())); }
+    mi_knn_sharded* handle() const { return h_; }
 };
+
+// the body of the scan loop and the query on HIP streams (BASELINE config 4; INTEGRATION.md section 2b)
+class Pipeline {
+    mi_pipeline* h_ = nullptr;
+
+   public:
+    Pipeline(clip_vit_large_patch14::Model& model, EmbeddingTable& table) { check(mi_pipeline_create(model.handle(), table.handle(), &h_)); }
+    // ONE process over several GPUs: models[s] is the tower replica on the device of shard s
+    Pipeline(const std::vector<clip_vit_large_patch14::Model*>& models, ShardedTable& table) {
+        std::vector<mi_clip*> hs;
+        for (auto* m : models) hs.push_back(m->handle());
+        check(mi_pipeline_create_sharded(hs.data(), (int)hs.size(), table.handle(), &h_));
+    }
+    Pipeline(const Pipeline&) = delete;
+    ~Pipeline() { mi_pipeline_free(h_); }
+    // [n,3,H,W] f32 (pinned memory from mi_host_alloc makes the upload asynchronous): returns the id of the first new row
+    uint64_t ingest(const float* nchw, size_t n) {
+        uint64_t first = 0;
+        check(mi_pipeline_ingest(h_, nchw, n, &first));
+        return first;
+    }
+    // results land in idx / dist when sync() (or drain) returns
+    void query(const float* q, uint32_t k, uint64_t* idx, float* dist) { check(mi_pipeline_query(h_, q, k, idx, dist)); }
+    void sync() { check(mi_pipeline_sync(h_)); }
+    // deliver finished queries until at most `leave_pending` remain (the ingest stream is not waited for)
+    void drain(uint32_t leave_pending = 0) { check(mi_pipeline_drain(h_, leave_pending)); }
+};
+
 
 }  // namespace image_search

@@ -71,6 +71,26 @@ int main(int argc, char** argv) {
         const auto a = one.knn(q, 50), b = st.knn(q, 50);
         EXPECT(a.first == b.first);
         EXPECT(std::memcmp(a.second.data(), b.second.data(), 50 * sizeof(float)) == 0);
+        // round 3: searches in flight, a live change of layout (device to device), a crash-safe save / load
+        std::vector<uint64_t> ai(50), bi(50);
+        std::vector<float> ad(50), bd(50);
+        std::vector<float> q2(768, 0.0f); q2[7] = 1.0f;
+        st.knn_async(q.data(), 50, ai.data(), ad.data());
+        st.knn_async(q2.data(), 50, bi.data(), bd.data());
+        st.sync();
+        EXPECT(ai == a.first && std::memcmp(ad.data(), a.second.data(), 50 * sizeof(float)) == 0);
+        EXPECT(bi[0] == 7);
+        ShardedTable two(768, {0, 0}, 128);
+        two.rebalance_from(st);
+        EXPECT(two.size() == 200);
+        const auto c = two.knn(q, 50);
+        EXPECT(c.first == a.first && std::memcmp(c.second.data(), a.second.data(), 50 * sizeof(float)) == 0);
+        const std::string prefix = std::string(argc > 2 ? argv[2] : "/tmp") + "/cpp_sharded";
+        two.save(prefix);
+        ShardedTable back(768, {0, 0, 0, 0}, 64);          // another layout: re-dealt on load
+        back.load(prefix);
+        const auto d = back.knn(q, 50);
+        EXPECT(back.size() == 200 && d.first == a.first);
     } else if (mi_device_count() == 0) {
         bool threw = false;
         try { EmbeddingTable t(768, 0); } catch (const std::runtime_error& e) { threw = std::strstr(e.what(), "no CPU fallback") != nullptr; }

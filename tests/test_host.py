@@ -245,5 +245,5 @@ def test_cpp_host_mirror_reference_unit_tests(mi, tmp_path):
 def test_cpp_host_mirror_on_gpu(mi, tmp_path):
     import subprocess
     exe = _build_cpp_host_test(tmp_path)
-    out = subprocess.run([exe, "gpu"], capture_output=True, text=True)
+    out = subprocess.run([exe, "gpu", str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
