@@ -122,16 +122,14 @@ struct mi_knn {
     size_t mirror_cap = 0, xx_cap = 0;
     uint64_t g8_rows = 0;              // rows the table held when the channel scales were taken (refreshed at 4x)
     // Feedback of the two-stage search, read back asynchronously (a query or two late, never a host block): after two
-    // consecutive fallbacks, or when the median of the last candidate counts exceeds 2^20, stage 1 is skipped for the
-    // next PREF_SKIP single-query searches and then probed again — a corpus the mirror cannot thin out pays the single
+    // consecutive fallbacks stage 1 is skipped for the next PREF_SKIP single-query searches and then probed again — a corpus the mirror cannot thin out pays the single
     // pass, not stage 1 on top of it ("prefilter_adaptive" = 0 turns this off).
     static constexpr int PREF_RING = 8, PREF_SKIP = 64;
     bool pref_adaptive = true;
     uint32_t* h_pref_ring = nullptr;   // pinned [PREF_RING][2]: {candidates, fell back}
     hipEvent_t pref_ev[PREF_RING] = {};
     bool pref_ev_pending[PREF_RING] = {};
-    uint32_t pref_hist[PREF_RING] = {};
-    uint32_t pref_hist_n = 0, pref_consec = 0, pref_skip_left = 0;
+    uint32_t pref_consec = 0, pref_skip_left = 0;
     // behind a skip window exactly two probes go out; until both have reported, later queries keep to the single pass
     // (a caller that enqueues faster than the device answers must not queue dozens of probes behind the first two)
     bool pref_probing = false;

@@ -178,9 +178,9 @@ int mi_knn_set_base(mi_knn* t, uint64_t base);
  * same ids, same distance bits, a half (1) or a quarter (2) of the bytes per query.  Corpora that put more than 2^22
  * rows inside the bound fall back to the single pass on the device.  0 (default) frees the mirror.
  * "prefilter_adaptive" = 1 (default) / 0: the two-stage search watches itself — candidate counts and fallbacks are read
- * back asynchronously; after two consecutive fallbacks, or when the median of the recent candidate counts exceeds 2^20, the
- * next 64 single-query searches run the single pass alone (what such a corpus would pay anyway, without stage 1 on top),
- * then stage 1 is probed again.  Results never change.  The channel scales of the byte mirror are taken again (and the
+ * back asynchronously; after two consecutive fallbacks (more than 2^22 candidates) the next 64 single-query searches run
+ * the single pass alone (what such a corpus would pay anyway, without stage 1 on top), then stage 1 is probed again with
+ * two queries.  Results never change.  The channel scales of the byte mirror are taken again (and the
  * mirror rebuilt, 10 ms per 10 M rows) when the table has grown 4x since they were taken. */
 int mi_knn_set_option(mi_knn* t, const char* key, int value);
 /* Of the most recent single-query search of this shard (waits for it): how many rows stage 2 re-evaluated, and whether the
