@@ -77,7 +77,7 @@ struct mi_clip {
     bool full_last = false;   // compute the dead rows of the last layer too (A/B against the reference graph)
     bool split_tail = true;   // cut a short last round of GEMM tiles into quadrant tasks
     bool text_fast = true;    // one text query (n == 1, CLIP-L text geometry, bf16): the skinny-GEMM path (vit.hip forward_text_one)
-    bool ln_nt = true;        // LN1 writes the residual stream back with the non-temporal hint (not read again before the next LayerNorm: -0.1 ms per forward, A/B in one call; MI_CLIP_LN_NT=0 | option "ln_nt" to switch off)
+    int ln_nt = 0;            // A/B hook (MI_CLIP_LN_NT / option "ln_nt"): bit 0 = LN1 writes the residual stream back non-temporally, bit 1 = LN1's last-use loads non-temporal; measured within noise, off
     bool im2col_rows = true;  // bf16 tower: the LDS-staged patch gather (im2col_rows_kernel); 0 = the 4P-byte-run form (A/B)
     mi::WorkOrder order;          // serialises this handle's enqueued work across caller streams
     std::mutex mu;

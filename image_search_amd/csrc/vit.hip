@@ -326,7 +326,7 @@ void layer_norm(mi_clip* m, float* x, const bf16_t* d1, const bf16_t* d2, bool w
     if (m->precision == MI_PRECISION_F32) {
         MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<float, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (float*)y, w, b, (int)rows, m->eps, y_ld, 0));
     } else if (write_back) {
-        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, y_ld, split, m->ln_nt ? 1 : 0));
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, y_ld, split, m->ln_nt));
     } else {
         MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, false>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, y_ld, split));
     }
@@ -728,7 +728,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         else if (k == "split_tail") m->split_tail = value != 0;
         else if (k == "im2col_rows") m->im2col_rows = value != 0;
         else if (k == "text_fast") m->text_fast = value != 0;
-        else if (k == "ln_nt") m->ln_nt = value != 0;
+        else if (k == "ln_nt") m->ln_nt = value & 3;
         else if (k == "max_batch") {
             if (value < 1) fail(MI_ERR_INVALID, "max_batch must be >= 1");
             m->max_batch = (size_t)value;
@@ -769,7 +769,7 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         if (const char* e = std::getenv("MI_CLIP_ATTN")) m->attn_ver = std::atoi(e) == 1 ? 1 : 2;  // fixed at load: decides the q scale
         if (const char* e = std::getenv("MI_GEMM_SPLIT")) m->split_tail = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_CLIP_IM2COL")) m->im2col_rows = std::atoi(e) != 0;
-        if (const char* e = std::getenv("MI_CLIP_LN_NT")) m->ln_nt = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MI_CLIP_LN_NT")) m->ln_nt = std::atoi(e) & 3;
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         m->n_cu = prop.multiProcessorCount;

@@ -187,6 +187,34 @@ struct LnRow {
 #pragma unroll
         for (int t = 0; t < NT; ++t) ld_vec<VEC>(&v[t * VEC], p + (t * 64 + lane) * VEC);
     }
+    // last-use loads (LN1: the residual stream and the two deltas are not read again): non-temporal hint
+    __device__ __forceinline__ void load_nt(const float* __restrict__ p, int lane) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if constexpr (VEC == 4) {
+                const v4f u = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p + (t * 64 + lane) * VEC));
+                v[t * 4 + 0] = u.x; v[t * 4 + 1] = u.y; v[t * 4 + 2] = u.z; v[t * 4 + 3] = u.w;
+            } else {
+                ld_vec<VEC>(&v[t * VEC], p + (t * 64 + lane) * VEC);
+            }
+        }
+    }
+    __device__ __forceinline__ void add_bf16_nt(const bf16_t* __restrict__ p, int lane) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16_t* q = p + (t * 64 + lane) * VEC;
+            if constexpr (VEC == 4) {
+                const v2u u = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(q));
+                v[t * 4 + 0] += __uint_as_float(u.x << 16); v[t * 4 + 1] += __uint_as_float(u.x & 0xffff0000u);
+                v[t * 4 + 2] += __uint_as_float(u.y << 16); v[t * 4 + 3] += __uint_as_float(u.y & 0xffff0000u);
+            } else if constexpr (VEC == 2) {
+                const uint32_t u = *reinterpret_cast<const uint32_t*>(q);
+                v[t * 2 + 0] += __uint_as_float(u << 16); v[t * 2 + 1] += __uint_as_float(u & 0xffff0000u);
+            } else {
+                v[t] += bf2f(*q);
+            }
+        }
+    }
     __device__ __forceinline__ void add(const float* __restrict__ p, int lane) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -265,11 +293,17 @@ __device__ __forceinline__ void ln_body(float* __restrict__ x, const bf16_t* __r
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     LnRow<VEC, NT> r;
-    r.load(x + (size_t)row * D, lane);
-    if (d1) r.add_bf16(d1 + (size_t)row * D, lane);
-    if (d2) r.add_bf16(d2 + (size_t)row * D, lane);
+    if (WRITE_BACK && (nt_x & 2)) {  // LN1, A/B: every operand is a last use
+        r.load_nt(x + (size_t)row * D, lane);
+        if (d1) r.add_bf16_nt(d1 + (size_t)row * D, lane);
+        if (d2) r.add_bf16_nt(d2 + (size_t)row * D, lane);
+    } else {
+        r.load(x + (size_t)row * D, lane);
+        if (d1) r.add_bf16(d1 + (size_t)row * D, lane);
+        if (d2) r.add_bf16(d2 + (size_t)row * D, lane);
+    }
     if (WRITE_BACK && (d1 || d2)) {
-        if (nt_x) r.store_nt(x + (size_t)row * D, lane);
+        if (nt_x & 1) r.store_nt(x + (size_t)row * D, lane);
         else r.store(x + (size_t)row * D, lane);
     }
     r.normalize(w, b, eps, lane);

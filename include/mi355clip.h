@@ -98,7 +98,8 @@ int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* nee
  *                only for queries whose softmax numerators leave the exponent range; same result)
  *   "split_tail" 0 = do not cut a short last round of GEMM tiles into quadrant tasks (A/B hook)
  *   "im2col_rows" 0 = the patch gather in 4P-byte runs instead of the LDS-staged rows form (A/B hook; same bits)
- *   "ln_nt"      0 = LN1 writes the residual stream back with ordinary stores instead of non-temporal ones (A/B hook; same bits)
+ *   "ln_nt"      bit 0 = LN1 writes the residual stream back with non-temporal stores, bit 1 = LN1's last-use loads are
+ *                non-temporal (A/B hook, default 0; same bits, no measurable effect)
  *   "text_fast"  0 = a single text query takes the batched kernels instead of the skinny-GEMM path (text handles) */
 int mi_clip_set_option(mi_clip* m, const char* key, int value);
 
