@@ -247,3 +247,27 @@ def test_cpp_host_mirror_on_gpu(mi, tmp_path):
     exe = _build_cpp_host_test(tmp_path)
     out = subprocess.run([exe, "gpu", str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+def test_round3_entry_points_return_codes_for_bad_arguments(mi):
+    """Nothing may abort or throw across the ABI (the reference panics / aborts on errors, server/Cargo.toml:9 — a drop-in
+    must not): the entry points added in round 3, called with null handles and impossible arguments on a box with or
+    without a GPU, answer with MI_ERR_INVALID and a message."""
+    import ctypes
+    from image_search_amd._lib import c_vp
+    u64 = ctypes.c_uint64()
+    buf = (ctypes.c_uint64 * 8)()
+    fbuf = (ctypes.c_float * 8)()
+    h = c_vp()
+    assert mi.mi_knn_sharded_append_device(None, None, 1, 0, None, ctypes.byref(u64)) == -1
+    assert mi.mi_knn_sharded_search_async(None, None, 1, 1, None, None) == -1
+    assert mi.mi_knn_sharded_sync(None) == -1
+    assert mi.mi_knn_sharded_rebalance(None, None) == -1
+    assert mi.mi_knn_sharded_shard(None, 0) is None
+    assert mi.mi_pipeline_create_sharded(None, 0, None, ctypes.byref(h)) == -1 and not h.value
+    assert mi.mi_pipeline_query_device(None, None, 1, None, None, None) == -1
+    assert mi.mi_knn_merge_device(0, buf, fbuf, 2, 1, 0, buf, fbuf, None) == -1          # k = 0
+    assert mi.mi_knn_merge_device(0, None, None, 2, 1, 4, None, None, None) == -1        # null buffers
+    assert mi.mi_knn_prefilter_state(None, None) == -1
+    assert mi.mi_op_clock_probe(0, None, None) == -1
+    assert b"null" in mi.mi_last_error().lower() or len(mi.mi_last_error()) > 0
