@@ -221,7 +221,10 @@ def sharded_probe(args) -> int:
     n = len(devices)
     rows_per_shard, batch = 1_000_000, args.batch
     cfg = synth.VitConfig.vit_l14()
-    wpath = os.path.join(tempfile.gettempdir(), "mi355clip_bench_vitl14_seed0.safetensors")
+    wpath, own_weights = os.environ.get("MI_BENCH_WEIGHTS", ""), False   # the parent bench's file, or (run by hand) one of its own
+    if not wpath or not os.path.exists(wpath):
+        wpath, own_weights = os.path.join(tempfile.gettempdir(), f"mi355clip_bench_vitl14_seed0_{os.getpid()}.safetensors"), True
+        synth.save_safetensors(synth.vit_weights(cfg, 0), wpath, {"num_attention_heads": cfg.heads})
     out = {"devices": devices, "shards": n}
     # 1. the search: small table against one mi_knn (bit equality), then rows_per_shard per shard (timing)
     small = ShardedTable(768, devices, 256)
@@ -234,6 +237,7 @@ def sharded_probe(args) -> int:
         a, b = small.knn(qs, k), one.knn(qs, k)
         eq = eq and bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)))
     out["transport"] = small.info()["transport"]
+    out["exchange_stats"] = small.stats()   # collectives > 0 <=> the library's own ncclAllGather ran (distinct devices)
     out["equal_to_one_table"] = eq
     small.close(); one.close()
     big = ShardedTable(768, devices, batch)
@@ -281,15 +285,17 @@ def sharded_probe(args) -> int:
     big.close()
     for pb in pins:
         pb.close()
+    if own_weights:
+        os.unlink(wpath)
     print("SHARDED_PROBE " + json.dumps(out), flush=True)
     return 0
 
 
-def run_sharded_probe(args):
+def run_sharded_probe(args, wpath):
     """the probe as a CHILD with its own deadline: a hang in a multi-GPU runtime call must not take the N = 1 line with it"""
     cmd = [sys.executable, os.path.abspath(__file__), "--sharded-probe", "--batch", str(args.batch), "--k", str(args.k)]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, MI_BENCH_WEIGHTS=wpath))
     except subprocess.TimeoutExpired:
         return {"error": "timed out after 240 s"}
     for ln in r.stdout.splitlines():
@@ -334,6 +340,9 @@ def dry_run(args, world, rank):
 
 def main():
     args = parse_args()
+    # dmabuf IPC: RCCL between processes needs it on this driver.  Set before torch / HIP is loaded, so that the documented
+    # `python -m torch.distributed.run ... bench.py` form gets it as the self-launch form does.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)  # nothing above imported torch or touched HIP
 
@@ -373,7 +382,9 @@ def main():
 
     # ---- untimed setup -------------------------------------------------------------
     cfg = synth.VitConfig.vit_l14()
-    wpath = os.path.join(tempfile.gettempdir(), "mi355clip_bench_vitl14_seed0.safetensors")
+    # one file per run (two benches on one box must not race on it): the rendezvous port names a multi-rank job, the pid a single one
+    job = os.environ.get("MASTER_PORT", "") if world > 1 else ""
+    wpath = os.path.join(tempfile.gettempdir(), f"mi355clip_bench_vitl14_seed0_{job or os.getpid()}.safetensors")
     weights = None
     if rank == 0:
         t0 = time.time()
@@ -390,8 +401,9 @@ def main():
     for j, pb in enumerate(pins):
         pb.array[:] = synth.preprocess_rgb8(synth.images_u8(1000 + 2 * rank + j, args.batch, cfg.image))
 
-    table = EmbeddingTable(768, local, base=rank * (args.rows + total_steps * args.batch))
-    table.reserve(args.rows + total_steps * args.batch)  # the appended rows never reallocate the table
+    appended = (2 * total_steps + 1) * args.batch          # the headline loop, then the same steps with the single-pass query
+    table = EmbeddingTable(768, local, base=rank * (args.rows + appended))
+    table.reserve(args.rows + appended)  # the appended rows never reallocate the table
     table.insert_synthetic(0, rank * args.rows, args.rows)
     if not args.no_prefilter:
         table.set_option("prefilter", args.prefilter)  # the mirror is built by the first (warm-up) query and caught up by every later one
@@ -432,28 +444,41 @@ def main():
         consume(0)
         pending.clear()
 
+    def timed(first, n):
+        """exactly n steps between barrier + synchronize on both sides; the maximum over ranks"""
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(first + i)
+        finish()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for i in range(args.warmup):
         step(i)
     finish()
     pipe.stats(reset=True)
     merged.clear()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    finish()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = timed(args.warmup, args.steps)
     n_f, ms_f, n_s, ms_s = pipe.stats()
+    n_merged = len(merged)
+    # The same steps once more with the query as ONE pass over the fp32 rows (the kernel that carries the kNN roofline
+    # credit): `value_single_pass_query`.  Behind the headline loop, never inside it; the table was reserved for these rows too.
+    elapsed_single = None
+    if not args.no_prefilter:
+        table.set_option("prefilter", 0)
+        step(total_steps)
+        finish()
+        elapsed_single = timed(total_steps + 1, args.steps)
+        table.set_option("prefilter", args.prefilter)
+        del merged[n_merged:]
     ms_vit = ms_f / max(n_f, 1)          # HIP events on the ingest stream around each forward, timed region only
     ms_knn_overlapped = ms_s / max(n_s, 1)
     exchange_check = None
@@ -600,6 +625,8 @@ def main():
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "value_single_pass_query": round(imgs / elapsed_single, 2) if elapsed_single else None,
+            "ms_per_step_single_pass_query": round(elapsed_single / args.steps * 1e3, 3) if elapsed_single else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"BASELINE config 4: per step, H2D of a pinned batch of {args.batch} 224x224x3 f32 images -> bf16 ViT-L/14 "
@@ -631,6 +658,8 @@ def main():
                          "achieved": round(tf_exec, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf_exec / PEAK_BF16_TFLOPS, 4),
                          "traffic": pmc.get("vit_hbm_bytes") if traffic_ok else None,
+                         "traffic_source": "profiles/pmc_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                           "(tools/round_profile.sh), NOT an observation of this run; fabric-side bytes incl. Infinity-Cache hits",
                          "executed_gflop_per_image": round(executed / 1e9, 2),
                          "algorithmic_gflop_per_image": round(VIT_FLOP_PER_IMAGE / 1e9, 2),
                          "frac_on_algorithmic_flops": round(tf_alg / PEAK_BF16_TFLOPS, 4),
@@ -641,6 +670,7 @@ def main():
                              "achieved": round(knn_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": round(knn_gbs / PEAK_HBM_GBS, 4),
                              "traffic": pmc.get("knn_scan_hbm_bytes") if traffic_ok else None,
+                             "traffic_source": "profiles/pmc_latest.json (separate --pmc passes of this command, not this run)",
                              "note": "the single-pass scan over the fp32 rows: algorithmic bytes = rows x 768 x 4"},
         }
         if ms_knn_two:
@@ -663,7 +693,7 @@ def main():
         if world == 1 and not args.no_extra_configs:
             # the ONE-process form (mi_knn_sharded + mi_pipeline_create_sharded) over every GPU this process can see, as a
             # child with its own deadline; on a one-GPU box: two shards and two replicas on GPU 0
-            out.setdefault("other_configs", {})["one_process_sharded"] = run_sharded_probe(args)
+            out.setdefault("other_configs", {})["one_process_sharded"] = run_sharded_probe(args, wpath)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(weights, cfg)
         failed = failed or two_stage_equal is False
@@ -673,6 +703,12 @@ def main():
     table.close()
     for pb in pins:
         pb.close()
+    barrier()
+    if rank == 0:
+        try:
+            os.unlink(wpath)
+        except OSError:
+            pass
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

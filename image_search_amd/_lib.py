@@ -59,6 +59,7 @@ SYMBOLS = {
     "mi_knn_sharded_free": (None, [c_vp]),
     "mi_knn_sharded_info": (ctypes.c_int, [c_vp, c_u64p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
                                            ctypes.POINTER(ctypes.c_int)]),
+    "mi_knn_sharded_stats": (ctypes.c_int, [c_vp, c_u64p]),
     "mi_knn_sharded_reserve": (ctypes.c_int, [c_vp, ctypes.c_uint64]),
     "mi_knn_sharded_set_option": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
     "mi_knn_sharded_append": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint64, c_u64p]),

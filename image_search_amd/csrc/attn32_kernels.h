@@ -56,14 +56,6 @@ __device__ __forceinline__ bf16x8 pack8(const v16f& s, int base) {
 
 constexpr float ATTN32_C2 = 0.125f * 1.4426950408889634f;  // scale * log2(e)
 
-// Diagnostic builds only (tools/probe/attn_bench.hip -DATTN32_ABL=mask): take one cost out of the static sweep to
-// see what it was worth.  1 no exp2, 2 numerators not packed (constant P; keeps the score MFMAs alive), 4 K/V
-// fragments read from LDS once per tile sweep, 8 no row-sum MFMAs, 16 waves 4-7 skip their whole tile, 32 no split
-// tile, 64 no LDS-DMA after the first pair, 128 no ctx stores, 256 query loads with coalesced addresses (8 lanes
-// per row), 512 ctx stores with coalesced addresses.  Results are wrong by construction; the library is built with 0.
-#ifndef ATTN32_ABL
-#define ATTN32_ABL 0
-#endif
 #ifndef ATTN32_QSPREAD
 #define ATTN32_QSPREAD 1  // the next pair's query fragments: one load per key step (1) or all four behind the barrier (0)
 #endif
@@ -229,10 +221,9 @@ __device__ __forceinline__ void attn32_sweep_static(const unsigned char* __restr
         const bool last = t + 1 == NKT;
         const bool one_key = last && ONE_KEY;
         const bool ragged = last && (S_CT % 32) != 0;
-        bf16x8 (&kn)[4] = kf[(ATTN32_ABL & 4) ? 0 : (t + 1) & 1];  // tile t + 1, read during step t - 1
+        bf16x8 (&kn)[4] = kf[(t + 1) & 1];  // tile t + 1, read during step t - 1
         hook(t);  // the caller's per-step work (one piece of the next pair's LDS-DMA, one of its query loads)
         // this step's V fragments (used by its last MFMAs) and the K fragments of the step after next, up front
-        if (!(ATTN32_ABL & 4) || t == 0)
 #pragma unroll
         for (int kp = 0; kp < (one_key ? 1 : 2); ++kp)
 #pragma unroll
@@ -261,7 +252,7 @@ __device__ __forceinline__ void attn32_sweep_static(const unsigned char* __restr
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int e = 4 * ks + j;
-                    float p = (ATTN32_ABL & 1) ? cur[e] : __builtin_amdgcn_exp2f(cur[e]);
+                    float p = __builtin_amdgcn_exp2f(cur[e]);
                     if (ragged) {
                         const int key = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
                         p = key < S_CT ? p : 0.0f;
@@ -273,21 +264,19 @@ __device__ __forceinline__ void attn32_sweep_static(const unsigned char* __restr
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < NKT && !(ATTN32_ABL & 4)) load_k(kf[t & 1], t + 2);  // the slot of tile t is free once its scores exist (previous step)
+        if (t + 2 < NKT) load_k(kf[t & 1], t + 2);  // the slot of tile t is free once its scores exist (previous step)
         bf16x8 p0 = pack8(cur, 0);
-        if (ATTN32_ABL & 2) { p0 = ones; p0[0] = (__bf16)cur[0]; }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][0], p0, o[dt], 0, 0, 0);
-        if (!(ATTN32_ABL & 8)) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p0, lsum, 0, 0, 0);
+        lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p0, lsum, 0, 0, 0);
         if (!one_key) {
             bf16x8 p1 = pack8(cur, 8);
-            if (ATTN32_ABL & 2) { p1 = ones; p1[0] = (__bf16)cur[8]; }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][1], p1, o[dt], 0, 0, 0);
-            if (!(ATTN32_ABL & 8)) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p1, lsum, 0, 0, 0);
+            lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p1, lsum, 0, 0, 0);
         }
     }
-    l += (ATTN32_ABL & 8) ? 1.0f : lsum[0];  // every row of ones x P is the column sum over all keys: complete in every lane
+    l += lsum[0];  // every row of ones x P is the column sum over all keys: complete in every lane
 }
 
 // The split query's partial over ONE full key tile, two tiles at a time (independent chains interleave): scores, the
@@ -447,12 +436,6 @@ __device__ __forceinline__ void attn32_store(const v16f (&o)[2], float inv, bf16
             const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
             v4u d;
             d.x = rx[0]; d.y = ry[0]; d.z = rx[1]; d.w = ry[1];
-            if (ATTN32_ABL & 128) { asm volatile("" :: "v"(d)); continue; }
-            if (ATTN32_ABL & 512) {
-                const int row0 = qrow - (lane & 31);
-                if (valid) *reinterpret_cast<v4u*>(ctx_b + (size_t)(row0 + 8 * (2 * dt + kk) + (lane >> 3)) * D + 8 * (lane & 7)) = d;
-                continue;
-            }
             if (valid) *reinterpret_cast<v4u*>(ctx_b + (size_t)qrow * D + 32 * dt + 16 * kk + 8 * h) = d;
         }
 }
@@ -478,11 +461,12 @@ __host__ __device__ constexpr int attn32_lds_bytes(int s_pad) { return 2 * (2 * 
 // and left in LDS.  They are combined one iteration later, behind the next top-of-loop barrier, so no barrier
 // sits inside an iteration and no wave waits for the slowest one there.  cls_only (last layer): only query 0 is needed: tile 0 alone, whole, by wave 0.
 // S_PAD: key rows of one LDS image (multiple of 32, <= 288).  S_CT > 0: compile-time token count.
-#ifdef ATTN32_STAMPS   // tools/probe/attn_bench.hip -DATTN32_STAMPS: per-segment shader cycles of every workgroup (diagnostic build only)
-__device__ unsigned long long* attn32_stamp_buf;
-#define ATTN32_STAMP(SLOT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (lane == 0) acc_[SLOT] += now_ - last_; last_ = __builtin_amdgcn_s_memtime(); }
-#else
+// Timing hooks: empty here.  A probe (tools/probe/attn_stamps.h) may define the three macros BEFORE including this header
+// to read the shader clock at the marked points of every workgroup; the library never does.
+#ifndef ATTN32_STAMP
+#define ATTN32_STAMP_BEGIN
 #define ATTN32_STAMP(SLOT)
+#define ATTN32_STAMP_END
 #endif
 #define ATTN32_BARRIER { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); }
 template <int S_PAD, int S_CT, bool PRESCALED>
@@ -504,7 +488,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
     // split job: one live query in its tile (S = 32 k + 1: the last token).  cls_only (last layer): only token 0 is
     // needed; its tile is taken WHOLE by wave 0, through the very code path the full layer uses for that tile, so
     // that the CLS-only last layer stays bit-identical to the full one (tests/test_vit_gpu.py)
-    const bool split = !(ATTN32_ABL & 32) && !cls_only && nqt == 9 && (S & 31) == 1;
+    const bool split = !cls_only && nqt == 9 && (S & 31) == 1;
     const int split_row = S - 1;
     const int n_whole = cls_only ? 1 : (split ? 8 : nqt);
 
@@ -541,11 +525,6 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
     auto load_q_raw = [&](bf16x8 (&q)[4], const Pair& pr, int qrow) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ATTN32_ABL & 256) {
-                const int row0 = qrow - r;  // tile base (the last tile's clamp makes this approximate: timing only)
-                q[ks] = *reinterpret_cast<const bf16x8*>(pr.base + (size_t)max(row0 + 8 * ks + (lane >> 3), 0) * ld + 8 * (lane & 7));
-                continue;
-            }
             q[ks] = *reinterpret_cast<const bf16x8*>(pr.base + (size_t)qrow * ld + 16 * ks + 8 * h);
         }
     };
@@ -578,9 +557,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
 
     int pair = blockIdx.x;
     if (pair >= n_pairs) return;
-#ifdef ATTN32_STAMPS
-    unsigned long long acc_[6] = {0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
-#endif
+    ATTN32_STAMP_BEGIN
     Pair cur = pair_of(pair);
     bf16x8 qa_n[4];               // the NEXT pair's query fragments of this wave's tile, loaded an iteration ahead
     v4u qs_n = {0u, 0u, 0u, 0u};  // wave 7, lanes 0-7: the split query's row of the NEXT pair on its way to LDS
@@ -600,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         // this pair's K, V and queries have landed once every wave has waited for its own loads: younger than
         // them are only the ctx stores of the previous iteration (4 per wave that owns a full tile), which stay in flight
         // (raw s_barrier: __syncthreads() would add vmcnt(0) and drain the stores and, further down, the next pair's DMA)
-        if (it == 0 || !four_stores || (ATTN32_ABL & 128)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (it == 0 || !four_stores) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         ATTN32_STAMP(0)   // own DMA / loads landed
         ATTN32_BARRIER
@@ -624,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         // pieces wave, wave + 8, ... go out one per key-tile step of the sweep below, the rest right after it
         int piece = wave;
         auto dma_hook = [&] {
-            if (more && piece < NPIECE && !(ATTN32_ABL & 64)) dma_piece(nxt, b ^ 1, piece);
+            if (more && piece < NPIECE) dma_piece(nxt, b ^ 1, piece);
             piece += 8;
         };
         // (all eight waves issuing their four 32-line query loads at once right behind the barrier cost the younger wave
@@ -645,7 +622,6 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         };
         // ---- whole tiles: tile w, w + 8, ... of this wave
         for (int qt = wave; qt < n_whole; qt += 8) {
-            if ((ATTN32_ABL & 16) && wave >= 4) break;
             if (qt != wave) {  // only when S > 256 without the split (generic shapes): fetch that tile's queries now
                 load_q_raw(qa, cur, min(32 * qt + r, S - 1));
                 scale_q(qa);
@@ -656,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
             if (!shifted) {
                 if constexpr (S_CT > 0) attn32_sweep_static<S_CT, false>(Ks, Vs, qa, 0.0f, lane, o, l, dma_q_hook);
                 else attn32_sweep<S_CT, false>(Ks, Vs, qa, 0.0f, S_rt, 0, 1, lane, o, l, dma_hook);
-                shifted = !ATTN32_ABL && __any(!(l > ATTN32_L_LO && l < ATTN32_L_HI));  // (ablation builds compute garbage: no second pass for it)
+                shifted = __any(!(l > ATTN32_L_LO && l < ATTN32_L_HI));
             }
             if (shifted) {  // rare: a numerator left the exponent range (or the caller asked for the shifted pass)
                 clear();
@@ -694,12 +670,8 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         const int last_it = (n_pairs - 1 - (int)blockIdx.x) / G;
         if (wave == 1) combine(scratch + (last_it & 1) * ATTN32_PART, ctx_prev);
     }
-#ifdef ATTN32_STAMPS
-    if (lane == 0)
-        for (int j = 0; j < 5; ++j) attn32_stamp_buf[((size_t)blockIdx.x * 8 + wave) * 8 + j] = acc_[j];
-#endif
+    ATTN32_STAMP_END
 }
 #undef ATTN32_BARRIER
-#undef ATTN32_STAMP
 
 }  // namespace mi

@@ -45,6 +45,10 @@ struct mi_clip {
     } act[4];
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    static constexpr int N_EV_SCHED = 256;   // events that tie the R stream and the LayerNorm streams of a scheduled forward (a ring, created on first use)
+    hipEvent_t ev_sched[N_EV_SCHED] = {};
+    int part0_short = 0;      // two-part forward: the first part takes n/2 - part0_short images (option "part0_short")
+    int sched = 0;            // how a two-part forward is ordered on the chip (forward() in vit.hip; option "sched" / MI_CLIP_SCHED)
     int parts = 2;  // MI_CLIP_PARTS: sub-chunks run as independent streams
     int n_cu = 256;
     uint8_t* d_rgb = nullptr;
@@ -177,10 +181,11 @@ struct PinnedBuf2 {
 // one search in flight on a sharded table: per-shard query / result buffers, the gathered lists and the merged result
 // on the first shard's device, pinned copies for the host, and where the caller wants them
 struct ShardedSlot {
-    std::vector<DevBuf> d_q, d_idx, d_dist;   // [shard]
-    std::vector<DevBuf> g_idx, g_dist;        // [shard] (RCCL receive side) or [0] only (copy transport)
-    DevBuf m_idx, m_dist;                     // merged, on shard 0's device
-    PinnedBuf2 h_q, h_idx, h_dist;
+    // a shard's answer is one packed record [nq*k x u64 id | nq*k x f32 distance] (padded to 16 bytes)
+    std::vector<DevBuf> d_q, d_rec;           // [shard]
+    std::vector<DevBuf> g_rec;                // [shard] (RCCL receive side: n records) or [0] only (copy transport)
+    DevBuf m_rec;                             // merged record, on shard 0's device
+    PinnedBuf2 h_q, h_rec;
     std::vector<hipEvent_t> ev;               // [shard]: list of shard s is in place
     hipEvent_t done = nullptr;
     uint32_t nq = 0, k = 0;
@@ -200,6 +205,7 @@ struct mi_knn_sharded {
     int next_slot = 0;
     std::vector<ncclComm_t> comms;
     bool use_rccl = false;
+    struct { uint64_t searches = 0, collectives = 0, copies = 0, merges = 0; } stats;   // mi_knn_sharded_stats
     uint64_t generation = 0;                  // of the files last saved or loaded (mi_knn_sharded_save)
     std::vector<hipEvent_t> ev_src;           // [device ordinal]: the peer copies of the last append_device from that device
     std::mutex mu;
@@ -217,8 +223,9 @@ hipStream_t knn_own_stream(mi_knn* t);
 void knn_grow(mi_knn* t, uint64_t want_rows);       // may reallocate: waits for the handle's pending work
 void knn_search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s);
 void knn_truncate(mi_knn* t, uint64_t rows);        // forget the rows behind `rows` (a failed multi-shard append / load rolls back)
+// list l of query u: ids at d_idx_in + l * idx_stride + u * k, distances at d_dist_in + l * dist_stride + u * k (elements)
 void knn_merge_lists_device(const uint64_t* d_idx_in, const float* d_dist_in, uint32_t lists, uint32_t nq, uint32_t k,
-                            uint64_t* d_idx, float* d_dist, hipStream_t s);   // caller has the device selected
+                            size_t idx_stride, size_t dist_stride, uint64_t* d_idx, float* d_dist, hipStream_t s);   // caller has the device selected
 // sharded.hip
 void sharded_place(const mi_knn_sharded* t, uint64_t r, uint32_t* s, uint64_t* local);
 uint64_t sharded_rows_of(const mi_knn_sharded* t, uint64_t total, uint32_t s);  // rows shard s holds when the table holds `total`

@@ -514,11 +514,14 @@ void knn_truncate(mi_knn* t, uint64_t rows) {
     t->mirror_rows = std::min(t->mirror_rows, rows);
 }
 void knn_merge_lists_device(const uint64_t* d_idx_in, const float* d_dist_in, uint32_t lists, uint32_t nq, uint32_t k,
-                            uint64_t* d_idx, float* d_dist, hipStream_t s) {
+                            size_t idx_stride, size_t dist_stride, uint64_t* d_idx, float* d_dist, hipStream_t s) {
     const uint32_t threads = std::max<uint32_t>(lists * k, k);
-    hipLaunchKernelGGL(knn_merge_lists_kernel, dim3((threads + 255) / 256, nq), dim3(256), 0, s, d_idx_in, d_dist_in, lists, k,
-                       (size_t)nq * k, d_idx, d_dist);
-    HIP_CHECK(hipGetLastError());
+    for (uint32_t u0 = 0; u0 < nq; u0 += 65535) {  // grid.y holds 65535 queries
+        const uint32_t nu = std::min<uint32_t>(65535, nq - u0);
+        hipLaunchKernelGGL(knn_merge_lists_kernel, dim3((threads + 255) / 256, nu), dim3(256), 0, s, d_idx_in + (size_t)u0 * k,
+                           d_dist_in + (size_t)u0 * k, lists, k, idx_stride, dist_stride, d_idx + (size_t)u0 * k, d_dist + (size_t)u0 * k);
+        HIP_CHECK(hipGetLastError());
+    }
 }
 }  // namespace mi
 
@@ -866,9 +869,9 @@ int mi_knn_merge_device(int device, const uint64_t* d_idx_in, const float* d_dis
         if (k == 0) fail(MI_ERR_INVALID, "k must be >= 1");
         if (nq == 0) return;
         if (!d_idx || !d_dist || (lists && (!d_idx_in || !d_dist_in))) fail(MI_ERR_INVALID, "null argument");
-        if ((uint64_t)lists * k > 0xFFFFFFFFull || nq > 65535) fail(MI_ERR_UNSUPPORTED, "lists * k or nq too large");
+        if ((uint64_t)lists * k > 0xFFFFFFFFull) fail(MI_ERR_UNSUPPORTED, "lists * k too large");
         DeviceGuard g(device);
-        knn_merge_lists_device(d_idx_in, d_dist_in, lists, nq, k, d_idx, d_dist, (hipStream_t)stream);
+        knn_merge_lists_device(d_idx_in, d_dist_in, lists, nq, k, (size_t)nq * k, (size_t)nq * k, d_idx, d_dist, (hipStream_t)stream);
     });
 }
 

@@ -1207,7 +1207,7 @@ __device__ __forceinline__ bool merge_less(uint32_t ka, uint64_t ia, uint32_t kb
     return ka < kb || (ka == kb && ia < ib);
 }
 __global__ __launch_bounds__(256) void knn_merge_lists_kernel(const uint64_t* __restrict__ idx_in, const float* __restrict__ dist_in,
-                                                              uint32_t lists, uint32_t k, size_t list_stride,
+                                                              uint32_t lists, uint32_t k, size_t idx_stride, size_t dist_stride,
                                                               uint64_t* __restrict__ idx, float* __restrict__ dist) {
     const uint32_t u = blockIdx.y;  // query
     const uint64_t* qi = idx_in + (size_t)u * k;
@@ -1216,7 +1216,7 @@ __global__ __launch_bounds__(256) void knn_merge_lists_kernel(const uint64_t* __
     if (e < k) {  // slots behind the last real entry: "none"
         uint32_t valid = 0;
         for (uint32_t l = 0; l < lists; ++l) {
-            const uint64_t* li = qi + l * list_stride;
+            const uint64_t* li = qi + l * idx_stride;
             uint32_t lo = 0, hi = k;  // first NO_ID of the list
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
@@ -1231,15 +1231,15 @@ __global__ __launch_bounds__(256) void knn_merge_lists_kernel(const uint64_t* __
     }
     if (e >= lists * k) return;
     const uint32_t l = e / k, p = e % k;
-    const uint64_t id = qi[l * list_stride + p];
+    const uint64_t id = qi[l * idx_stride + p];
     if (id == MI_KNN_NO_ID) return;
-    const float d = qd[l * list_stride + p];
+    const float d = qd[l * dist_stride + p];
     const uint32_t key = dist_to_u32(d);
     uint32_t rank = p;
     for (uint32_t o = 0; o < lists && rank < k; ++o) {
         if (o == l) continue;
-        const uint64_t* li = qi + o * list_stride;
-        const float* ld = qd + o * list_stride;
+        const uint64_t* li = qi + o * idx_stride;
+        const float* ld = qd + o * dist_stride;
         uint32_t lo = 0, hi = k;  // entries of list o in front of this one
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;

@@ -44,7 +44,7 @@ using namespace mi;
 namespace {
 
 // ---- RCCL, bound at run time -------------------------------------------------------------------
-enum { kNcclUint64 = 5, kNcclFloat32 = 7 };
+enum { kNcclUint8 = 1 };  // ncclDataType_t: the packed records travel as bytes
 struct Rccl {
     void* lib = nullptr;
     int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
@@ -89,14 +89,14 @@ void free_sharded(mi_knn_sharded* t) {
     for (auto& sl : t->slots) {
         for (size_t s = 0; s < t->shard.size(); ++s) {
             (void)hipSetDevice(t->devices[s]);
-            for (std::vector<DevBuf>* v : {&sl.d_q, &sl.d_idx, &sl.d_dist, &sl.g_idx, &sl.g_dist})
+            for (std::vector<DevBuf>* v : {&sl.d_q, &sl.d_rec, &sl.g_rec})
                 if (s < v->size() && (*v)[s].p) (void)hipFree((*v)[s].p);
             if (s < sl.ev.size() && sl.ev[s]) (void)hipEventDestroy(sl.ev[s]);
         }
         if (!t->devices.empty()) (void)hipSetDevice(t->devices[0]);
-        for (DevBuf* b : {&sl.m_idx, &sl.m_dist})
+        for (DevBuf* b : {&sl.m_rec})
             if (b->p) (void)hipFree(b->p);
-        for (PinnedBuf2* b : {&sl.h_q, &sl.h_idx, &sl.h_dist})
+        for (PinnedBuf2* b : {&sl.h_q, &sl.h_rec})
             if (b->p) (void)hipHostFree(b->p);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
@@ -140,8 +140,8 @@ void deliver(ShardedSlot& sl) {
     if (!sl.busy) return;
     HIP_CHECK(hipEventSynchronize(sl.done));
     const size_t per = (size_t)sl.nq * sl.k;
-    std::memcpy(sl.user_idx, sl.h_idx.p, per * 8);
-    std::memcpy(sl.user_dist, sl.h_dist.p, per * 4);
+    std::memcpy(sl.user_idx, sl.h_rec.p, per * 8);
+    std::memcpy(sl.user_dist, (const char*)sl.h_rec.p + per * 8, per * 4);
     sl.busy = false;
 }
 
@@ -149,15 +149,23 @@ void deliver(ShardedSlot& sl) {
 void append_device_locked(mi_knn_sharded* t, const float* d_rows, uint64_t n, int src_device, hipStream_t st) {
     std::vector<char> touched(t->n(), 0);
     try {
+        // Every shard that receives rows is taken to its FINAL size before any copy is enqueued: a reallocation in the
+        // middle of the call would move (and free) a table that this call's earlier copies, still queued on the producer's
+        // stream, are writing into — grow() only waits for the work recorded by EARLIER calls.
+        for (uint32_t s = 0; s < t->n(); ++s) {
+            mi_knn* sh = t->shard[s];
+            const uint64_t want = sharded_rows_of(t, t->rows + n, s);
+            if (want == sh->rows) continue;
+            std::lock_guard<std::mutex> ls(sh->mu);
+            DeviceGuard gs(sh->device);
+            knn_grow(sh, want);  // a reallocation waits for the shard's work in flight (reserve ahead to avoid it)
+        }
         for_runs(t, t->rows, n, [&](uint64_t r, uint64_t len, uint32_t s, uint64_t local) {
             mi_knn* sh = t->shard[s];
             std::lock_guard<std::mutex> ls(sh->mu);
             if (local != sh->rows) fail(MI_ERR_INVALID, "shard %u out of step (%llu rows, expected %llu)", s,
                                         (unsigned long long)sh->rows, (unsigned long long)local);
-            {
-                DeviceGuard gs(sh->device);
-                knn_grow(sh, sh->rows + len);  // a reallocation waits for the shard's work in flight (reserve ahead to avoid it)
-            }
+            if (sh->rows + len > sh->cap) fail(MI_ERR_INVALID, "shard %u was not grown for this append", s);
             DeviceGuard g(src_device);
             sh->writes.begin(st);
             const float* src = d_rows + (r - t->rows) * t->dim;
@@ -246,21 +254,27 @@ void sharded_deliver_all(mi_knn_sharded* t) {
 // Replaces `SELECT id, image_path, vector::distance::knn() FROM image WHERE embedding <|K|> $reference`
 // (server/src/search.rs:70-86) over all shards; same results and ordering as ONE mi_knn holding every row.
 // Enqueues everything and returns; the results reach idx / dist when the slot is delivered.
+//
+// A shard's answer is ONE packed record [nq*k x u64 id | nq*k x f32 distance], padded to 16 bytes: the scan writes both
+// halves in place, the exchange moves it as one piece — one ncclAllGather of bytes per shard (or one copy) — the merge
+// kernel reads the gathered records where they lie, and the merged record goes to the host in one copy.
 void sharded_search_enqueue(mi_knn_sharded* t, const float* q, uint32_t nq, uint32_t k, uint64_t* idx, float* dist) {
     const uint32_t n = t->n();
-    const size_t per = (size_t)nq * k;  // results per shard
+    const size_t per = (size_t)nq * k;                        // results per shard
+    const size_t rec = (per * 12 + 15) / 16 * 16;             // bytes of one shard's packed record
+    auto rec_idx = [&](void* r) { return (uint64_t*)r; };
+    auto rec_dist = [&](void* r) { return (float*)((char*)r + per * 8); };
     ShardedSlot& sl = t->slots[t->next_slot];
     t->next_slot = (t->next_slot + 1) % mi_knn_sharded::N_SLOTS;
     deliver(sl);  // the ring is full only when N_SLOTS searches are pending: finish the oldest
     if (sl.d_q.empty()) {
-        sl.d_q.resize(n); sl.d_idx.resize(n); sl.d_dist.resize(n); sl.g_idx.resize(n); sl.g_dist.resize(n);
+        sl.d_q.resize(n); sl.d_rec.resize(n); sl.g_rec.resize(n);
         sl.ev.assign(n, nullptr);
     }
     sl.nq = nq; sl.k = k; sl.user_idx = idx; sl.user_dist = dist;
     sl.h_q.reserve((size_t)nq * t->dim * 4);
     std::memcpy(sl.h_q.p, q, (size_t)nq * t->dim * 4);
-    sl.h_idx.reserve(per * 8);
-    sl.h_dist.reserve(per * 4);
+    sl.h_rec.reserve(rec);
     // 1. every shard: query up, scan on the shard's own stream — the n scans run side by side
     for (uint32_t s = 0; s < n; ++s) {
         mi_knn* sh = t->shard[s];
@@ -268,52 +282,45 @@ void sharded_search_enqueue(mi_knn_sharded* t, const float* q, uint32_t nq, uint
         DeviceGuard g(sh->device);
         hipStream_t st = knn_own_stream(sh);
         grow_buf(sl.d_q[s], (size_t)nq * t->dim * 4, st);
-        grow_buf(sl.d_idx[s], per * 8, st);
-        grow_buf(sl.d_dist[s], per * 4, st);
+        grow_buf(sl.d_rec[s], rec, st);
         HIP_CHECK(hipMemcpyAsync(sl.d_q[s].p, sl.h_q.p, (size_t)nq * t->dim * 4, hipMemcpyHostToDevice, st));
         sh->writes.begin(st);
         sh->reads.begin(st);
         for (uint32_t u = 0; u < nq; ++u)
-            knn_search_one(sh, (const float*)sl.d_q[s].p + (size_t)u * t->dim, k, (uint64_t*)sl.d_idx[s].p + (size_t)u * k,
-                           (float*)sl.d_dist[s].p + (size_t)u * k, st);
+            knn_search_one(sh, (const float*)sl.d_q[s].p + (size_t)u * t->dim, k, rec_idx(sl.d_rec[s].p) + (size_t)u * k,
+                           rec_dist(sl.d_rec[s].p) + (size_t)u * k, st);
         sh->reads.end(st);
     }
     mi_knn* first = t->shard[0];
-    const uint64_t* res_idx = (const uint64_t*)sl.d_idx[0].p;
-    const float* res_dist = (const float*)sl.d_dist[0].p;
-    if (n > 1) {
-        // 2. the one exchange step: 12 k bytes per shard and query, [shard][query][k] on the first shard's device
+    void* result = sl.d_rec[0].p;
+    ++t->stats.searches;
+    // A one-shard table gathers nothing — unless it was made with the RCCL transport (MI_KNN_SHARDED_TRANSPORT=rccl): then
+    // its one-rank communicator runs the same collective and merge as n ranks do (how a one-GPU box exercises that code).
+    if (n > 1 || t->use_rccl) {
+        // 2. the one exchange step: 12 k bytes per shard and query, [shard] records on the first shard's device
         if (t->use_rccl) {
             for (uint32_t s = 0; s < n; ++s) {
                 DeviceGuard g(t->shard[s]->device);
-                grow_buf(sl.g_idx[s], per * n * 8, t->shard[s]->stream);
-                grow_buf(sl.g_dist[s], per * n * 4, t->shard[s]->stream);
+                grow_buf(sl.g_rec[s], rec * n, t->shard[s]->stream);
             }
             RCCL_CHECK(rccl().GroupStart());
             for (uint32_t s = 0; s < n; ++s) {
-                hipStream_t st = t->shard[s]->stream;
-                RCCL_CHECK(rccl().AllGather(sl.d_idx[s].p, sl.g_idx[s].p, per, kNcclUint64, t->comms[s], st));
-                RCCL_CHECK(rccl().AllGather(sl.d_dist[s].p, sl.g_dist[s].p, per, kNcclFloat32, t->comms[s], st));
+                RCCL_CHECK(rccl().AllGather(sl.d_rec[s].p, sl.g_rec[s].p, rec, kNcclUint8, t->comms[s], t->shard[s]->stream));
+                ++t->stats.collectives;
             }
             RCCL_CHECK(rccl().GroupEnd());
         } else {
             {
                 DeviceGuard g(first->device);
-                grow_buf(sl.g_idx[0], per * n * 8, first->stream);
-                grow_buf(sl.g_dist[0], per * n * 4, first->stream);
+                grow_buf(sl.g_rec[0], rec * n, first->stream);
             }
             for (uint32_t s = 0; s < n; ++s) {
                 mi_knn* sh = t->shard[s];
                 DeviceGuard g(sh->device);
-                uint64_t* gi = (uint64_t*)sl.g_idx[0].p + per * s;
-                float* gd = (float*)sl.g_dist[0].p + per * s;
-                if (sh->device == first->device) {
-                    HIP_CHECK(hipMemcpyAsync(gi, sl.d_idx[s].p, per * 8, hipMemcpyDeviceToDevice, sh->stream));
-                    HIP_CHECK(hipMemcpyAsync(gd, sl.d_dist[s].p, per * 4, hipMemcpyDeviceToDevice, sh->stream));
-                } else {
-                    HIP_CHECK(hipMemcpyPeerAsync(gi, first->device, sl.d_idx[s].p, sh->device, per * 8, sh->stream));
-                    HIP_CHECK(hipMemcpyPeerAsync(gd, first->device, sl.d_dist[s].p, sh->device, per * 4, sh->stream));
-                }
+                char* dst = (char*)sl.g_rec[0].p + rec * s;
+                if (sh->device == first->device) HIP_CHECK(hipMemcpyAsync(dst, sl.d_rec[s].p, rec, hipMemcpyDeviceToDevice, sh->stream));
+                else HIP_CHECK(hipMemcpyPeerAsync(dst, first->device, sl.d_rec[s].p, sh->device, rec, sh->stream));
+                ++t->stats.copies;
                 if (s == 0) continue;
                 if (!sl.ev[s]) HIP_CHECK(hipEventCreateWithFlags(&sl.ev[s], hipEventDisableTiming));
                 HIP_CHECK(hipEventRecord(sl.ev[s], sh->stream));
@@ -321,18 +328,16 @@ void sharded_search_enqueue(mi_knn_sharded* t, const float* q, uint32_t nq, uint
             DeviceGuard g(first->device);
             for (uint32_t s = 1; s < n; ++s) HIP_CHECK(hipStreamWaitEvent(first->stream, sl.ev[s], 0));
         }
-        // 3. one merge per query over the n lists, on the first shard's device
+        // 3. one merge per query over the n lists, on the first shard's device, reading the records where they lie
         DeviceGuard g(first->device);
-        grow_buf(sl.m_idx, per * 8, first->stream);
-        grow_buf(sl.m_dist, per * 4, first->stream);
-        knn_merge_lists_device((const uint64_t*)sl.g_idx[0].p, (const float*)sl.g_dist[0].p, n, nq, k, (uint64_t*)sl.m_idx.p,
-                               (float*)sl.m_dist.p, first->stream);
-        res_idx = (const uint64_t*)sl.m_idx.p;
-        res_dist = (const float*)sl.m_dist.p;
+        grow_buf(sl.m_rec, rec, first->stream);
+        knn_merge_lists_device(rec_idx(sl.g_rec[0].p), rec_dist(sl.g_rec[0].p), n, nq, k, rec / 8, rec / 4, rec_idx(sl.m_rec.p),
+                               rec_dist(sl.m_rec.p), first->stream);
+        ++t->stats.merges;
+        result = sl.m_rec.p;
     }
     DeviceGuard g(first->device);
-    HIP_CHECK(hipMemcpyAsync(sl.h_idx.p, res_idx, per * 8, hipMemcpyDeviceToHost, first->stream));
-    HIP_CHECK(hipMemcpyAsync(sl.h_dist.p, res_dist, per * 4, hipMemcpyDeviceToHost, first->stream));
+    HIP_CHECK(hipMemcpyAsync(sl.h_rec.p, result, per * 12, hipMemcpyDeviceToHost, first->stream));
     if (!sl.done) HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     HIP_CHECK(hipEventRecord(sl.done, first->stream));
     sl.busy = true;
@@ -406,7 +411,17 @@ int mi_knn_sharded_info(const mi_knn_sharded* t, uint64_t* rows, uint32_t* n_sha
         if (rows) *rows = t->rows;
         if (n_shards) *n_shards = t->n();
         if (block_rows) *block_rows = t->block;
-        if (transport) *transport = t->n() == 1 ? 0 : (t->use_rccl ? 2 : 1);
+        if (transport) *transport = t->use_rccl ? 2 : (t->n() == 1 ? 0 : 1);
+    });
+}
+
+// {searches enqueued, ncclAllGather calls issued (one per shard and search), transport copies, device merges}: lets a
+// caller (and the tests) see which exchange code a search really ran
+int mi_knn_sharded_stats(const mi_knn_sharded* t, uint64_t out[4]) {
+    return guarded([&] {
+        if (!t || !out) fail(MI_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> l(const_cast<mi_knn_sharded*>(t)->mu);
+        out[0] = t->stats.searches; out[1] = t->stats.collectives; out[2] = t->stats.copies; out[3] = t->stats.merges;
     });
 }
 
@@ -510,6 +525,7 @@ static void check_sharded_search(const mi_knn_sharded* t, const float* q, uint32
     if (!t) fail(MI_ERR_INVALID, "null table handle");
     if (nq && (!q || !idx || !dist)) fail(MI_ERR_INVALID, "null query/result pointer");
     if (k == 0) fail(MI_ERR_INVALID, "k must be >= 1");
+    if ((uint64_t)t->n() * k > 0xFFFFFFFFull) fail(MI_ERR_UNSUPPORTED, "shards * k too large");
 }
 
 int mi_knn_sharded_search(mi_knn_sharded* t, const float* q, uint32_t nq, uint32_t k, uint64_t* idx, float* dist) {

@@ -218,7 +218,7 @@ void ensure_workspace(mi_clip* m, size_t n) {
     m->d_rgb = (uint8_t*)bytes(n * px);
     const int sets = (m->precision == MI_PRECISION_BF16) ? std::max(1, m->parts) : 1;
     for (int a = 0; a < sets; ++a) {
-        const size_t na = a == 0 ? n : (n + 1) / 2;
+        const size_t na = a == 0 ? n : (n + 1) / 2 + (size_t)m->part0_short;  // the second part takes what the first gives up
         const size_t Ma = pad256(na * m->S), Pa = pad256(na * (m->S - 1));
         if (na == 0) continue;
         m->act[a].col = bytes(Pa * m->Kp * es);
@@ -395,37 +395,65 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     const bool deferred = m->precision == MI_PRECISION_BF16;
     const int Kln = m->split_ln ? 2 * D : D;  // K of the GEMMs fed by a LayerNorm (q/k/v, fc1): hi | lo halves when split
     const int parts = (deferred && m->parts > 1 && n >= 32) ? m->parts : 1;
-    struct Part { size_t n, M, P; const float* img; float* out; hipStream_t s; mi_clip::Act* a; const bf16_t *p1, *p2; } pt[4];
+    // Scheduling of a two-part forward (option "sched").  The persistent GEMMs and attention need a whole CU's LDS: they
+    // exclude one another ("R" work); the LayerNorms need none and run beside them ("L" work).
+    //   0: every part on its own stream, nothing between them (the hardware queues arbitrate).
+    //   1: all R work of both parts on ONE stream in the order A.R1 B.R1 A.R2 B.R2 (R1 = qkv, attention, out_proj;
+    //      R2 = fc1, fc2), each part's LayerNorms on a stream of its own, tied to the R stream by events: a part's
+    //      LayerNorm always runs beside the other part's R block, and two GEMMs never share the chip.
+    //   2: every part on its own stream as in 0, R blocks chained across the streams by events in the same order.
+    const int sched = parts == 2 ? m->sched : 0;
+    struct Part { size_t n, M, P; const float* img; float* out; hipStream_t rs, ls; mi_clip::Act* a; const bf16_t *p1, *p2; } pt[4];
+    auto aux = [&](int i) {
+        if (!m->aux[i]) HIP_CHECK(hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking));
+        return m->aux[i];
+    };
     for (size_t p = 0, first = 0; p < (size_t)parts; ++p) {
-        const size_t np = n / parts + (p < n % parts ? 1 : 0);
-        pt[p] = {np, np * S, np * (S - 1), d_img + first * px, d_out + first * m->E, p == 0 ? s0 : m->aux[p - 1], &m->act[p], nullptr, nullptr};
+        size_t np = n / parts + (p < n % parts ? 1 : 0);
+        // two parts: the first may be given fewer images so that its token rows fill whole rounds of 256-row tiles
+        // (127 images = 32 639 rows = 128 row tiles = exactly 2 / 6 / 8 rounds of the four GEMMs on 256 CUs)
+        if (parts == 2 && m->part0_short > 0 && n > 2 * (size_t)m->part0_short) np = p == 0 ? n / 2 - m->part0_short : n - (n / 2 - m->part0_short);
+        hipStream_t rs = p == 0 ? s0 : nullptr, ls = nullptr;
+        if (sched == 1) { rs = s0; ls = aux(0); }  // ONE LayerNorm stream: in the intended order they never overlap one another
+        else { if (p > 0) rs = aux((int)p - 1); ls = rs; }
+        pt[p] = {np, np * S, np * (S - 1), d_img + first * px, d_out + first * m->E, rs, ls, &m->act[p], nullptr, nullptr};
         first += np;
     }
+    // Events are recorded the moment their producer is enqueued (an event recorded later would also cover whatever the
+    // stream was given in between — e.g. the other part's LayerNorm — and tie the consumer to that too).
+    int ev_next = 0;
+    auto post = [&](hipStream_t from) {
+        hipEvent_t& e = m->ev_sched[ev_next++ % mi_clip::N_EV_SCHED];
+        if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(e, from));
+        return e;
+    };
+    auto await = [&](hipStream_t to, hipEvent_t e) { if (e) HIP_CHECK(hipStreamWaitEvent(to, e, 0)); };
+    hipEvent_t ev_ln[4] = {}, ev_r[4] = {}, ev_rprev = nullptr;  // per part: its last LayerNorm / R block; sched 2: the last R block of any part
     if (parts > 1) {
-        for (int p = 1; p < parts; ++p)
-            if (!m->aux[p - 1]) {
-                HIP_CHECK(hipStreamCreateWithFlags(&m->aux[p - 1], hipStreamNonBlocking));
-                pt[p].s = m->aux[p - 1];
-            }
         HIP_CHECK(hipEventRecord(m->ev_fork, s0));
-        for (int p = 1; p < parts; ++p) HIP_CHECK(hipStreamWaitEvent(m->aux[p - 1], m->ev_fork, 0));
+        for (int p = 0; p < parts; ++p) {
+            if (pt[p].ls != s0) HIP_CHECK(hipStreamWaitEvent(pt[p].ls, m->ev_fork, 0));
+            if (pt[p].rs != s0 && pt[p].rs != pt[p].ls) HIP_CHECK(hipStreamWaitEvent(pt[p].rs, m->ev_fork, 0));
+        }
     }
     for (int p = 0; p < parts; ++p) {
         Part& q = pt[p];
+        hipStream_t fs = q.ls;  // the front of a part runs on its L stream
         // patch embedding: gather -> GEMM [P,Kp] x [D,Kp]^T -> f32
         const size_t total = q.P * 3 * (size_t)m->patch;  // one thread per patch-row segment
         const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65535 * 4);
         if (m->precision == MI_PRECISION_F32)
-            hipLaunchKernelGGL((im2col_kernel<float>), dim3(blocks), dim3(256), 0, q.s, q.img, (float*)q.a->col, (int)q.n, m->grid, m->patch, m->image, m->Kp);
+            hipLaunchKernelGGL((im2col_kernel<float>), dim3(blocks), dim3(256), 0, fs, q.img, (float*)q.a->col, (int)q.n, m->grid, m->patch, m->image, m->Kp);
         else if (m->im2col_rows && m->image % 4 == 0 && (3 * m->patch * m->patch) % 4 == 0 && m->Kp % 4 == 0 && (size_t)3 * m->patch * m->image * 4 <= 64 * 1024)
-            hipLaunchKernelGGL(im2col_rows_kernel, dim3((unsigned)(q.n * m->grid)), dim3(256), (size_t)3 * m->patch * m->image * 4, q.s, q.img,
+            hipLaunchKernelGGL(im2col_rows_kernel, dim3((unsigned)(q.n * m->grid)), dim3(256), (size_t)3 * m->patch * m->image * 4, fs, q.img,
                                (bf16_t*)q.a->col, m->grid, m->patch, m->image, m->Kp);
         else
-            hipLaunchKernelGGL((im2col_kernel<bf16_t>), dim3(blocks), dim3(256), 0, q.s, q.img, (bf16_t*)q.a->col, (int)q.n, m->grid, m->patch, m->image, m->Kp);
+            hipLaunchKernelGGL((im2col_kernel<bf16_t>), dim3(blocks), dim3(256), 0, fs, q.img, (bf16_t*)q.a->col, (int)q.n, m->grid, m->patch, m->image, m->Kp);
         HIP_CHECK(hipGetLastError());
-        gemm<EPI_STORE_F32>(m, q.a->col, m->wpatch, nullptr, q.a->patch, q.P, D, m->Kp, D, q.s);
+        gemm<EPI_STORE_F32>(m, q.a->col, m->wpatch, nullptr, q.a->patch, q.P, D, m->Kp, D, fs);
         const unsigned lb = (unsigned)((q.M + 3) / 4);
-        MI_LN_DISPATCH(D, hipLaunchKernelGGL((embed_ln_kernel<VEC, NT>), dim3(lb), dim3(256), 0, q.s, q.a->patch, m->cls, m->pos, q.a->x, m->pre_w, m->pre_b, (int)q.M, S, m->eps));
+        MI_LN_DISPATCH(D, hipLaunchKernelGGL((embed_ln_kernel<VEC, NT>), dim3(lb), dim3(256), 0, fs, q.a->patch, m->cls, m->pos, q.a->x, m->pre_w, m->pre_b, (int)q.M, S, m->eps));
         HIP_CHECK(hipGetLastError());
     }
     // fp32 path: the residual add is the GEMM epilogue (x += acc + bias, fp32 read-modify-write).
@@ -437,78 +465,122 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     // the head run on n rows instead of n*S (same arithmetic per row, so the same bits; the reference's
     // graph computes the other rows and discards them).  Option "full_last" keeps the full last layer.
     const bool full_last = m->full_last;
+    hipStream_t r_prev = nullptr;  // sched 2: the stream of the R block enqueued last
+    auto r_enter = [&](int p) {    // in front of an R block of part p
+        Part& q = pt[p];
+        if (q.ls != q.rs) await(q.rs, ev_ln[p]);                       // its LayerNorm output (sched 1)
+        if (sched == 2 && r_prev && r_prev != q.rs) await(q.rs, ev_rprev);
+    };
+    auto r_leave = [&](int p) {
+        Part& q = pt[p];
+        if (q.ls != q.rs) ev_r[p] = post(q.rs);
+        if (sched == 2) { ev_rprev = post(q.rs); r_prev = q.rs; }
+    };
+    auto ln_enter = [&](int p) { if (pt[p].ls != pt[p].rs) await(pt[p].ls, ev_r[p]); };
+    auto ln_leave = [&](int p) { if (pt[p].ls != pt[p].rs) ev_ln[p] = post(pt[p].ls); };
     for (size_t li = 0; li < m->layers.size(); ++li) {
         const Layer& ly = m->layers[li];
         const bool last = !full_last && li + 1 == m->layers.size();
+        // ---- LN1 (L), then R1 = qkv, attention[, out_proj]
         for (int p = 0; p < parts; ++p) {
             Part& q = pt[p];
-            layer_norm(m, q.a->x, q.p1, q.p2, true, q.a->y, ly.ln1w, ly.ln1b, q.M, q.s);
-            if (!last) {
-                gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, Kln, 3 * D, q.s);
-            } else {
+            ln_enter(p);
+            layer_norm(m, q.a->x, q.p1, q.p2, true, q.a->y, ly.ln1w, ly.ln1b, q.M, q.ls);
+            ln_leave(p);
+            if (sched == 0) {  // as launched since round 1: LN1, qkv, attention of every part, then the rest of every part
+                if (!last) gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, Kln, 3 * D, q.rs);
+            }
+            if (sched != 0 || last) continue;
+            attention(m, q.a->qkv, q.a->y, q.n, q.rs, false);
+        }
+        for (int p = 0; p < parts; ++p) {
+            Part& q = pt[p];
+            if (sched != 0) r_enter(p);
+            hipStream_t s = q.rs;
+            if (last) {
                 // keys and values of every token, queries of the CLS rows only (the other rows of the
                 // leading query tile keep whatever the buffer held: their context rows are never read)
                 const size_t es = esize(m);
-                gemm<EPI_BIAS>(m, q.a->y, (const char*)ly.wqkv + (size_t)D * Kln * es, ly.bqkv + D, (char*)q.a->qkv + (size_t)D * es, q.M, 2 * D, Kln, 3 * D, q.s);
+                gemm<EPI_BIAS>(m, q.a->y, (const char*)ly.wqkv + (size_t)D * Kln * es, ly.bqkv + D, (char*)q.a->qkv + (size_t)D * es, q.M, 2 * D, Kln, 3 * D, s);
                 const unsigned gb = (unsigned)std::min<size_t>((q.n * (size_t)D / 4 + 255) / 256, 4096);
-                if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, q.s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_y, (int)q.n, (size_t)S, Kln);
-                else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb), dim3(256), 0, q.s, (const float*)q.a->y, (float*)q.a->c_y, (int)q.n, (size_t)S, D);
-                gemm<EPI_BIAS>(m, q.a->c_y, ly.wqkv, ly.bqkv, q.a->c_ctx, q.n, D, Kln, D, q.s);
-                if (deferred) hipLaunchKernelGGL((scatter_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, q.s, (const bf16_t*)q.a->c_ctx, (bf16_t*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)3 * D);
-                else hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3(gb), dim3(256), 0, q.s, (const float*)q.a->c_ctx, (float*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)3 * D);
+                if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_y, (int)q.n, (size_t)S, Kln);
+                else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb), dim3(256), 0, s, (const float*)q.a->y, (float*)q.a->c_y, (int)q.n, (size_t)S, D);
+                gemm<EPI_BIAS>(m, q.a->c_y, ly.wqkv, ly.bqkv, q.a->c_ctx, q.n, D, Kln, D, s);
+                if (deferred) hipLaunchKernelGGL((scatter_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, (const bf16_t*)q.a->c_ctx, (bf16_t*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)3 * D);
+                else hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3(gb), dim3(256), 0, s, (const float*)q.a->c_ctx, (float*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)3 * D);
                 HIP_CHECK(hipGetLastError());
-            }
-            attention(m, q.a->qkv, q.a->y, q.n, q.s, last);
-        }
-        if (last) {
-            for (int p = 0; p < parts; ++p) {
-                Part& q = pt[p];
-                const unsigned gb = (unsigned)std::min<size_t>((q.n * (size_t)D / 4 + 255) / 256, 4096);
-                if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, q.s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_ctx, (int)q.n, (size_t)S, D);
-                else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb), dim3(256), 0, q.s, (const float*)q.a->y, (float*)q.a->c_ctx, (int)q.n, (size_t)S, D);
-                hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb), dim3(256), 0, q.s, (const float*)q.a->x, q.a->c_x, (int)q.n, (size_t)S, D);
+                attention(m, q.a->qkv, q.a->y, q.n, s, true);
+                // the rest of the last layer is a few hundred rows: it stays on the R stream, LayerNorm included
+                const unsigned gb2 = gb;
+                if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb2), dim3(256), 0, s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_ctx, (int)q.n, (size_t)S, D);
+                else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb2), dim3(256), 0, s, (const float*)q.a->y, (float*)q.a->c_ctx, (int)q.n, (size_t)S, D);
+                hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb2), dim3(256), 0, s, (const float*)q.a->x, q.a->c_x, (int)q.n, (size_t)S, D);
                 HIP_CHECK(hipGetLastError());
                 if (deferred) {
-                    gemm<EPI_BIAS>(m, q.a->c_ctx, ly.wo, ly.bo, q.a->c_d1, q.n, D, D, D, q.s);
-                    layer_norm(m, q.a->c_x, q.a->c_d1, nullptr, false, q.a->c_y, ly.ln2w, ly.ln2b, q.n, q.s);
-                    gemm<EPI_BIAS_QGELU>(m, q.a->c_y, ly.w1, ly.b1, q.a->c_h, q.n, FF, Kln, FF, q.s);
-                    gemm<EPI_BIAS>(m, q.a->c_h, ly.w2, ly.b2, q.a->c_d2, q.n, D, FF, D, q.s);
+                    gemm<EPI_BIAS>(m, q.a->c_ctx, ly.wo, ly.bo, q.a->c_d1, q.n, D, D, D, s);
+                    layer_norm(m, q.a->c_x, q.a->c_d1, nullptr, false, q.a->c_y, ly.ln2w, ly.ln2b, q.n, s);
+                    gemm<EPI_BIAS_QGELU>(m, q.a->c_y, ly.w1, ly.b1, q.a->c_h, q.n, FF, Kln, FF, s);
+                    gemm<EPI_BIAS>(m, q.a->c_h, ly.w2, ly.b2, q.a->c_d2, q.n, D, FF, D, s);
                 } else {
-                    gemm<EPI_BIAS_RESID>(m, q.a->c_ctx, ly.wo, ly.bo, q.a->c_x, q.n, D, D, D, q.s);
-                    layer_norm(m, q.a->c_x, nullptr, nullptr, true, q.a->c_y, ly.ln2w, ly.ln2b, q.n, q.s);
-                    gemm<EPI_BIAS_QGELU>(m, q.a->c_y, ly.w1, ly.b1, q.a->c_h, q.n, FF, Kln, FF, q.s);
-                    gemm<EPI_BIAS_RESID>(m, q.a->c_h, ly.w2, ly.b2, q.a->c_x, q.n, D, FF, D, q.s);
+                    gemm<EPI_BIAS_RESID>(m, q.a->c_ctx, ly.wo, ly.bo, q.a->c_x, q.n, D, D, D, s);
+                    layer_norm(m, q.a->c_x, nullptr, nullptr, true, q.a->c_y, ly.ln2w, ly.ln2b, q.n, s);
+                    gemm<EPI_BIAS_QGELU>(m, q.a->c_y, ly.w1, ly.b1, q.a->c_h, q.n, FF, Kln, FF, s);
+                    gemm<EPI_BIAS_RESID>(m, q.a->c_h, ly.w2, ly.b2, q.a->c_x, q.n, D, FF, D, s);
                 }
-                MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, q.s, q.a->c_x, deferred ? q.a->c_d1 : (const bf16_t*)nullptr, deferred ? q.a->c_d2 : (const bf16_t*)nullptr, m->post_w, m->post_b, m->proj, q.out, (int)q.n, 1, m->E, m->eps, (const int*)nullptr));
+                MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, s, q.a->c_x, deferred ? q.a->c_d1 : (const bf16_t*)nullptr, deferred ? q.a->c_d2 : (const bf16_t*)nullptr, m->post_w, m->post_b, m->proj, q.out, (int)q.n, 1, m->E, m->eps, (const int*)nullptr));
                 HIP_CHECK(hipGetLastError());
+                r_leave(p);
+                continue;
             }
-            break;
+            if (sched != 0) {
+                gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, Kln, 3 * D, s);
+                attention(m, q.a->qkv, q.a->y, q.n, s, false);
+            }
+            if (deferred) gemm<EPI_BIAS>(m, q.a->y, ly.wo, ly.bo, q.a->delta, q.M, D, D, D, s);
+            else gemm<EPI_BIAS_RESID>(m, q.a->y, ly.wo, ly.bo, q.a->x, q.M, D, D, D, s);
+            if (sched != 0) r_leave(p);
+            // ---- LN2 (L)
+            ln_enter(p);
+            if (deferred) layer_norm(m, q.a->x, q.a->delta, nullptr, false, q.a->y, ly.ln2w, ly.ln2b, q.M, q.ls);
+            else layer_norm(m, q.a->x, nullptr, nullptr, true, q.a->y, ly.ln2w, ly.ln2b, q.M, q.ls);
+            ln_leave(p);
+            if (sched == 0) {  // R2 right behind, on the part's own stream
+                gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, Kln, FF, s);
+                if (deferred) { gemm<EPI_BIAS>(m, q.a->h, ly.w2, ly.b2, q.a->delta2, q.M, D, FF, D, s); q.p1 = q.a->delta; q.p2 = q.a->delta2; }
+                else gemm<EPI_BIAS_RESID>(m, q.a->h, ly.w2, ly.b2, q.a->x, q.M, D, FF, D, s);
+            }
         }
-        for (int p = 0; p < parts; ++p) {
+        if (last) break;
+        // ---- R2 = fc1, fc2
+        for (int p = 0; p < parts && sched != 0; ++p) {
             Part& q = pt[p];
-            if (deferred) {
-                gemm<EPI_BIAS>(m, q.a->y, ly.wo, ly.bo, q.a->delta, q.M, D, D, D, q.s);
-                layer_norm(m, q.a->x, q.a->delta, nullptr, false, q.a->y, ly.ln2w, ly.ln2b, q.M, q.s);
-                gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, Kln, FF, q.s);
-                gemm<EPI_BIAS>(m, q.a->h, ly.w2, ly.b2, q.a->delta2, q.M, D, FF, D, q.s);
-                q.p1 = q.a->delta; q.p2 = q.a->delta2;
-            } else {
-                gemm<EPI_BIAS_RESID>(m, q.a->y, ly.wo, ly.bo, q.a->x, q.M, D, D, D, q.s);
-                layer_norm(m, q.a->x, nullptr, nullptr, true, q.a->y, ly.ln2w, ly.ln2b, q.M, q.s);
-                gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, Kln, FF, q.s);
-                gemm<EPI_BIAS_RESID>(m, q.a->h, ly.w2, ly.b2, q.a->x, q.M, D, FF, D, q.s);
-            }
+            r_enter(p);
+            hipStream_t s = q.rs;
+            gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, Kln, FF, s);
+            if (deferred) { gemm<EPI_BIAS>(m, q.a->h, ly.w2, ly.b2, q.a->delta2, q.M, D, FF, D, s); q.p1 = q.a->delta; q.p2 = q.a->delta2; }
+            else gemm<EPI_BIAS_RESID>(m, q.a->h, ly.w2, ly.b2, q.a->x, q.M, D, FF, D, s);
+            r_leave(p);
         }
     }
     for (int p = 0; p < parts && full_last; ++p) {
         Part& q = pt[p];
+        ln_enter(p);
         // fp32 in both precisions: the embedding that goes to the table is not rounded to bf16 anywhere here
-        MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, q.s, q.a->x, q.p1, q.p2, m->post_w, m->post_b, m->proj, q.out, (int)q.n, S, m->E, m->eps, (const int*)nullptr));
+        MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, q.ls, q.a->x, q.p1, q.p2, m->post_w, m->post_b, m->proj, q.out, (int)q.n, S, m->E, m->eps, (const int*)nullptr));
         HIP_CHECK(hipGetLastError());
     }
-    for (int p = 1; p < parts; ++p) {
-        HIP_CHECK(hipEventRecord(m->ev_join[p - 1], m->aux[p - 1]));
-        HIP_CHECK(hipStreamWaitEvent(s0, m->ev_join[p - 1], 0));
+    if (parts > 1) {
+        hipStream_t seen[8]; int ns = 0, j = 0;
+        for (int p = 0; p < parts; ++p)
+            for (hipStream_t st : {pt[p].rs, pt[p].ls}) {
+                bool dup = st == s0;
+                for (int i = 0; i < ns; ++i) dup = dup || seen[i] == st;
+                if (dup) continue;
+                seen[ns++] = st;
+                HIP_CHECK(hipEventRecord(m->ev_join[j], st));
+                HIP_CHECK(hipStreamWaitEvent(s0, m->ev_join[j], 0));
+                ++j;
+            }
     }
 }
 
@@ -625,8 +697,19 @@ void forward_text_one_graphed(mi_clip* m, hipStream_t s) {
         if (dead) (void)hipGraphDestroy(dead);
         throw;
     }
-    HIP_CHECK(hipStreamEndCapture(s, &m->text_graph));
-    HIP_CHECK(hipGraphInstantiate(&m->text_graph_exec, m->text_graph, nullptr, nullptr, 0));
+    // a capture or an instantiation that fails leaves nothing behind: the query is answered eagerly and the next call
+    // tries again from a clean state
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    if (hipStreamEndCapture(s, &g) != hipSuccess || !g || hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ge) (void)hipGraphExecDestroy(ge);
+        if (g) (void)hipGraphDestroy(g);
+        forward_text_one(m, s);
+        return;
+    }
+    m->text_graph = g;
+    m->text_graph_exec = ge;
     m->text_graph_state = 2;
     HIP_CHECK(hipGraphLaunch(m->text_graph_exec, s));
 }
@@ -670,6 +753,7 @@ void free_model(mi_clip* m) {
     for (auto& a : m->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
     m->order.destroy();
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    for (auto& e : m->ev_sched) if (e) (void)hipEventDestroy(e);
     for (auto& e : m->ev_join) if (e) (void)hipEventDestroy(e);
     if (m->copy_stream) { (void)hipStreamSynchronize(m->copy_stream); (void)hipStreamDestroy(m->copy_stream); }
     for (int b = 0; b < 2; ++b) {
@@ -708,6 +792,7 @@ int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* nee
             for (size_t i = 0; i < t.shape.size(); ++i) out += (i ? "," : "") + std::to_string(t.shape[i]);
             out += "]\n";
         }
+        for (const std::string& l : file->skipped_lines()) out += l + "\n";
         if (needed) *needed = out.size() + 1;
         if (buf && cap) {
             const size_t n = std::min(cap - 1, out.size());
@@ -723,12 +808,32 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         std::lock_guard<std::mutex> l(m->mu);
         DeviceGuard g(m->device);
         const std::string k(key);
+        // a captured text query has kernel arguments and launch choices baked in: any option may change them
+        if (m->text) { m->order.sync(); drop_text_graph(m); }
         if (k == "full_last") m->full_last = value != 0;
         else if (k == "attn_shift") m->attn_shift = value != 0;
         else if (k == "split_tail") m->split_tail = value != 0;
         else if (k == "im2col_rows") m->im2col_rows = value != 0;
         else if (k == "text_fast") m->text_fast = value != 0;
         else if (k == "ln_nt") m->ln_nt = value & 3;
+        else if (k == "grid_cus") {  // A/B hook: cap of the persistent kernels' grids (GEMM, attention); 0 = every CU
+            if (value < 0 || value > 4096) fail(MI_ERR_INVALID, "grid_cus out of range");
+            hipDeviceProp_t prop;
+            HIP_CHECK(hipGetDeviceProperties(&prop, m->device));
+            m->n_cu = value > 0 ? std::min(value, prop.multiProcessorCount) : prop.multiProcessorCount;
+        } else if (k == "part0_short") {
+            if (value < 0 || value > 64) fail(MI_ERR_INVALID, "part0_short must be 0..64");
+            if (value != m->part0_short) {  // the second activation set grows: rebuild on next use
+                m->order.sync();
+                for (void* p : m->ws) HIP_CHECK(hipFree(p));
+                m->ws.clear();
+                m->cap = 0;
+                m->part0_short = value;
+            }
+        } else if (k == "sched") {
+            if (value < 0 || value > 2) fail(MI_ERR_INVALID, "sched must be 0, 1 or 2");
+            m->sched = value;
+        }
         else if (k == "max_batch") {
             if (value < 1) fail(MI_ERR_INVALID, "max_batch must be >= 1");
             m->max_batch = (size_t)value;
@@ -742,7 +847,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, im2col_rows, ln_nt, text_fast, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, im2col_rows, ln_nt, sched, text_fast, max_batch, parts)", key);
     });
 }
 
@@ -770,6 +875,7 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         if (const char* e = std::getenv("MI_GEMM_SPLIT")) m->split_tail = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_CLIP_IM2COL")) m->im2col_rows = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_CLIP_LN_NT")) m->ln_nt = std::atoi(e) & 3;
+        if (const char* e = std::getenv("MI_CLIP_SCHED")) m->sched = std::min(2, std::max(0, std::atoi(e)));
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         m->n_cu = prop.multiProcessorCount;

@@ -977,12 +977,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
         const int h = (j >= 2) ? 1 : 0;
         unsigned char* dst = smem + buf * 65536 + (is_x ? 0 : 32768) + h * 16384 + wave * 2048;
         const uint32_t so = (is_x ? xs + x_wave + 64u * h * Kb : ws + w_wave + 32u * h * Kb) + (uint32_t)kt * 128u;
-#if defined(PP_ABL) && (PP_ABL & 1)  // probe builds only (tools/probe/gemm_bench.hip -DPP_ABL=mask): no operand DMA, LDS keeps what it holds
-        (void)so; (void)dst;
-#else
         glds16_buf(is_x ? xr : wr, x_lane, so, dst);
         glds16_buf(is_x ? xr : wr, x_lane, so + 8u * Kb, dst + 1024);
-#endif
     };
     unsigned char* bias_lds = smem + 131072 + 18432 + wave * 256;
     auto stage_bias = [&](int tn) {
@@ -1065,11 +1061,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
                 const int row = j * 8 + (lane >> 3);
                 const v4u d = *reinterpret_cast<const v4u*>(patch + row * 144 + (lane & 7) * 16);
                 const uint32_t so = o_tile + (uint32_t)(mi * 16 + j * 8) * (uint32_t)ldo * 2u;
-#if defined(PP_ABL) && (PP_ABL & 2)  // probe builds only: no output stores
-                asm volatile("" ::"v"(d), "v"(so));
-#else
                 __builtin_amdgcn_raw_buffer_store_b128(d, orr, o_lane, so, 0);
-#endif
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -1294,17 +1286,12 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 // (a, b); swap32: rows 2,3 <-> 0,1), so max(a', b') holds max(own, partner) in every lane -- no LDS
 // crossbar round trip (ds_bpermute) on the softmax's critical path.
 __device__ __forceinline__ float xmax_rows(float v) {
-#ifdef ATTN_SHFL_MAX
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
-#else
     const unsigned u = __float_as_uint(v);
     const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
     v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
     const unsigned w = __float_as_uint(v);
     const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
-#endif
 }
 
 // ------------------------------------------------------------------ attention, bf16 MFMA
@@ -1539,11 +1526,7 @@ __device__ __forceinline__ void attn_pair(const unsigned char* __restrict__ Ks, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float pw = 0.0f;
-#if defined(ABL) && ABL == 3
-            if (live) pw = __builtin_fmaf(sc[e], C2, mc);
-#else
             if (live) pw = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], C2, mc));
-#endif
             dst[4 * half + e] = (__bf16)pw;
         }
     };
@@ -1634,13 +1617,8 @@ __device__ __forceinline__ void attn_pair(const unsigned char* __restrict__ Ks, 
             if (s + 1 < NPV && 2 * (s + 1) < nkt) load_v(vfr[(s + 1) & 1], s + 1);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-#if defined(ABL) && ABL == 4
-                asm volatile("" ::"v"(vfr[s & 1][dt]), "v"(paA[s]));
-            sumA[0] = 1.0f;
-#else
                 oA[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[s & 1][dt], paA[s], oA[dt], 0, 0, 0);
             sumA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, paA[s], sumA, 0, 0, 0);
-#endif
         }
         exp_pack4(scB[2 * s], mcB, 2 * s < nkt, paB[s], 0);
         exp_pack4(scB[2 * s + 1], mcB, 2 * s + 1 < nkt, paB[s], 1);
@@ -1656,13 +1634,8 @@ __device__ __forceinline__ void attn_pair(const unsigned char* __restrict__ Ks, 
             if (s + 1 < NPV && 2 * (s + 1) < nkt) load_v(vfr[(s + 1) & 1], s + 1);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-#if defined(ABL) && ABL == 4
-                asm volatile("" ::"v"(vfr[s & 1][dt]), "v"(paB[s]));
-            sumB[0] = 1.0f;
-#else
                 oB[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[s & 1][dt], paB[s], oB[dt], 0, 0, 0);
             sumB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, paB[s], sumB, 0, 0, 0);
-#endif
         }
     }
     store_o(oB, sumB, qtB);
@@ -1680,7 +1653,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const size_t ld = (size_t)3 * D;
     const bf16_t* base = qkv + (size_t)b * S * ld + hh * 64;
 
-#if !defined(ABL) || ABL != 2  // ABL 2: no staging (LDS holds garbage)
     // K and V go HBM -> LDS by LDS-DMA, 8 rows (1 KiB) per wave-instruction; the image is linear,
     // the XOR swizzle is applied to the per-lane source chunk; rows >= S lie beyond the
     // descriptor's num_records, so the hardware range check fills them with zeros.
@@ -1695,12 +1667,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#endif
     __syncthreads();
-#if defined(ABL) && ABL == 1  // staging only
-    if (tid < 4) ctx[(size_t)blockIdx.x * 4 + tid] = *reinterpret_cast<const bf16_t*>(Ks + tid * 2);
-    return;
-#endif
 
     // query tiles of this wave: w', w'+4, ... with the start rotated between co-resident workgroups;
     // they are taken two at a time, a last odd one alone

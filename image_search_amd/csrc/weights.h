@@ -17,7 +17,15 @@
 //                that order implies, and anything else is refused with the inventory in the message.  Burn keeps
 //                Linear weights [d_in, d_out]: they are transposed on read (a [d_out, d_in] fc1/fc2/projection is
 //                recognised by its shape and left alone; square q/k/v/out weights are taken as Burn's).
-//                UNTESTED against a real burn-import file: tests use tools/make_synthetic_mpk.py.
+//                The graph the reference imports is an OPSET-16 export (clip/scripts/upgrade_opset.py:9-28): LayerNorm
+//                is decomposed there, so its gamma / beta are bare `constantN` parameters between Mul / Add nodes, not
+//                `layernormalizationN {gamma, beta}` modules, and the record may carry the decomposition's scalar
+//                constants and integer tensors (position ids, shapes).  The reader therefore (a) sets aside — and lists —
+//                leaves that cannot be a tower tensor (non-float dtype, fewer than 8 elements, a 1-D length that is
+//                neither D nor FF), (b) binds a bias to the matrix of its own module when there is one, and (c) places
+//                the remaining [D]-vectors in graph order; both the fused and the decomposed inventory, with the linears
+//                as Linear modules or as bare MatMul + Add constants, map to the same names.
+//                PARITY UNPINNED: no real burn-import file exists offline; tests use tools/make_synthetic_mpk.py.
 #pragma once
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -79,6 +87,7 @@ struct WeightFile {
     virtual const TensorInfo& info(const std::string& name) const = 0;       // shape in PyTorch convention ([out, in])
     virtual std::vector<float> read(const std::string& name, int64_t numel) const = 0;
     virtual std::vector<std::string> names() const = 0;                      // in file order
+    virtual std::vector<std::string> skipped_lines() const { return {}; }    // "(set aside) path dtype [shape]" of leaves that map to no tensor
 };
 
 // ------------------------------------------------------------------ safetensors
@@ -415,6 +424,10 @@ struct BurnMpk : WeightFile {
         mapped[name] = m;
         order.push_back(name);
     }
+    static std::string parent_of(const std::string& path) {
+        const size_t dot = path.find_last_of('.');
+        return dot == std::string::npos ? std::string() : path.substr(0, dot);
+    }
     void map_names() {
         if (raws.empty()) bad("no tensor inside");
         // (1) a record that already carries the Hugging Face names
@@ -424,7 +437,7 @@ struct BurnMpk : WeightFile {
             for (size_t i = 0; i < raws.size(); ++i) put(raws[i].path, i, false, raws[i].shape);
             return;
         }
-        // (2) shape and order (see the header of this file)
+        // (2) shape, module and order (see the header of this file)
         size_t conv = raws.size();
         for (size_t i = 0; i < raws.size(); ++i)
             if (raws[i].shape.size() == 4 && raws[i].shape[1] == 3 && raws[i].shape[2] == raws[i].shape[3]) {
@@ -433,10 +446,22 @@ struct BurnMpk : WeightFile {
             }
         if (conv == raws.size()) fail(MI_ERR_UNSUPPORTED, "'%s': no [D,3,P,P] patch-embedding tensor — not a CLIP vision tower record: %s", path_.c_str(), inventory().c_str());
         const int64_t D = raws[conv].shape[0];
+        // Leaves that cannot be a tensor of the tower are set aside (and listed), not filed under a role: the graph the
+        // reference builds is an opset-16 export (clip/scripts/upgrade_opset.py:9-28), whose LayerNorms are decomposed —
+        // the record then also carries what the decomposition's Pow / Add / Sqrt / Mul nodes and the attention's scale and
+        // the QuickGELU's 1.702 hold (rank-0 / [1] floats), the position ids and Reshape shapes (integers).
+        //   * a dtype that is not F32 / F16 / BF16;   * fewer elements than the smallest tower dimension can have (< 8).
+        std::vector<char> skip_leaf(raws.size(), 0);
+        for (size_t i = 0; i < raws.size(); ++i) {
+            int64_t numel = 1;
+            for (auto d : raws[i].shape) numel *= d;
+            const bool is_float = raws[i].dtype == "F32" || raws[i].dtype == "F16" || raws[i].dtype == "BF16";
+            if (i != conv && (!is_float || numel < 8)) { skip_leaf[i] = 1; skipped.push_back(i); }
+        }
         std::vector<size_t> vecD, vecF, sq, wide, tall, pos, other;
         int64_t FF = 0;
         for (size_t i = 0; i < raws.size(); ++i) {
-            if (i == conv) continue;
+            if (i == conv || skip_leaf[i]) continue;
             const std::vector<int64_t> s = squeeze(raws[i].shape);
             if (s.size() == 1 && s[0] == D) vecD.push_back(i);
             else if (s.size() == 1) { vecF.push_back(i); }
@@ -459,12 +484,52 @@ struct BurnMpk : WeightFile {
             else if (kv.second == 1) E = kv.first;
         }
         if (L == 1 && count_by_o.size() == 1 && count_by_o.begin()->second == 3) FF = E = count_by_o.begin()->first;  // FF == E, one layer
-        if (!FF || !E || other.size() != 2 * L + 1 || pos.size() != 1 || vecD.size() != 9 * L + 5 || vecF.size() != L)
+        // a 1-D float vector that is neither [D] nor [FF] belongs to nothing in the tower: set aside too
+        if (FF) {
+            std::vector<size_t> keep;
+            for (size_t i : vecF) {
+                if (squeeze(raws[i].shape)[0] == FF) keep.push_back(i);
+                else { skip_leaf[i] = 1; skipped.push_back(i); }
+            }
+            vecF.swap(keep);
+        }
+        // A bias that sits in the same module as a matrix (burn-import's Linear: {weight [in,out], bias [out]}) is BOUND to
+        // that matrix, wherever the module stands in the record; every other [D]-vector is a bare constant — the
+        // class embedding, the affine parameters of a decomposed LayerNorm (Mul by gamma, then Add beta: graph order), the
+        // gamma / beta of a fused LayerNorm module, or the bias of a MatMul + Add pair that was not coalesced into a Linear —
+        // and takes its place in graph order among the bare ones.
+        std::map<std::string, size_t> matrix_of_module;   // module path -> raw index of its 2-D tensor
+        std::map<std::string, int> matrices_in_module;
+        for (const std::vector<size_t>* grp : {&sq, &other})
+            for (size_t i : *grp) { const std::string par = parent_of(raws[i].path); matrix_of_module[par] = i; ++matrices_in_module[par]; }
+        std::map<size_t, size_t> bias_of_matrix;          // matrix raw index -> bias raw index
+        auto bind = [&](std::vector<size_t>& vecs, int64_t want_out_or_any) {
+            std::vector<size_t> bare;
+            for (size_t i : vecs) {
+                const std::string par = parent_of(raws[i].path);
+                auto it = par.empty() ? matrix_of_module.end() : matrix_of_module.find(par);
+                if (it != matrix_of_module.end() && matrices_in_module[par] == 1 && !bias_of_matrix.count(it->second)) {
+                    const auto ms = squeeze(raws[it->second].shape);
+                    const int64_t len = squeeze(raws[i].shape)[0];
+                    if (ms[0] == len || ms[1] == len) { bias_of_matrix[it->second] = i; continue; }
+                }
+                bare.push_back(i);
+            }
+            (void)want_out_or_any;
+            vecs.swap(bare);
+        };
+        bind(vecD, D);
+        bind(vecF, FF);
+        const size_t bound = bias_of_matrix.size();
+        const bool all_bound = bound == 6 * L, none_bound = bound == 0;   // q, k, v, out, fc1, fc2 per layer (the projection has no bias)
+        const size_t want_bare_D = all_bound ? 4 * L + 5 : 9 * L + 5, want_bare_F = all_bound ? 0 : L;
+        if (!FF || !E || other.size() != 2 * L + 1 || pos.size() != 1 || !(all_bound || none_bound) || vecD.size() != want_bare_D || vecF.size() != want_bare_F)
             fail(MI_ERR_UNSUPPORTED,
                  "'%s': the tensor inventory does not match a CLIP vision tower in graph order (layers %zu from the [D,D] count; "
-                 "[D]-vectors %zu, want %zu; fc1 biases %zu, want %zu; fc/projection matrices %zu, want %zu; position tables %zu, want 1): %s",
-                 path_.c_str(), L, vecD.size(), 9 * L + 5, vecF.size(), L, other.size(), 2 * L + 1, pos.size(), inventory().c_str());
-        for (size_t i : vecF) if (squeeze(raws[i].shape)[0] != FF) fail(MI_ERR_UNSUPPORTED, "'%s': a vector of %lld elements among the fc1 biases (FF = %lld)", path_.c_str(), (long long)squeeze(raws[i].shape)[0], (long long)FF);
+                 "biases bound to a matrix of their module %zu, want 0 or %zu; bare [D]-vectors %zu, want %zu; bare fc1 biases %zu, want %zu; "
+                 "fc/projection matrices %zu, want %zu; position tables %zu, want 1; leaves set aside %zu): %s",
+                 path_.c_str(), L, bound, 6 * L, vecD.size(), want_bare_D, vecF.size(), want_bare_F, other.size(), 2 * L + 1, pos.size(),
+                 skipped.size(), inventory().c_str());
         const std::string v = "vision_model.";
         put(v + "embeddings.patch_embedding.weight", conv, false, raws[conv].shape);
         put(v + "embeddings.position_embedding.weight", pos[0], false, squeeze(raws[pos[0]].shape));
@@ -477,25 +542,40 @@ struct BurnMpk : WeightFile {
             if (!burn && !(s[0] == d_out && s[1] == d_in)) fail(MI_ERR_UNSUPPORTED, "'%s': '%s' is not a %lld x %lld matrix either way", path_.c_str(), raws[raw].path.c_str(), (long long)d_out, (long long)d_in);
             put(name, raw, burn, {d_out, d_in});
         };
+        // weight + bias of one linear layer: the bias bound to the matrix, or the next bare vector of its length
+        auto linear = [&](const std::string& base, size_t raw, int64_t d_out, int64_t d_in) {
+            lin(base + ".weight", raw, d_out, d_in);
+            auto it = bias_of_matrix.find(raw);
+            if (it != bias_of_matrix.end()) {
+                if (squeeze(raws[it->second].shape)[0] != d_out) fail(MI_ERR_UNSUPPORTED, "'%s': '%s' is not a bias of %lld elements", path_.c_str(), raws[it->second].path.c_str(), (long long)d_out);
+                put(base + ".bias", it->second, false, {d_out});
+            } else if (d_out == D) vec(base + ".bias");
+            else put(base + ".bias", vecF[vf++], false, {FF});
+        };
         vec(v + "embeddings.class_embedding");
         vec(v + "pre_layrnorm.weight");
         vec(v + "pre_layrnorm.bias");
         for (size_t l = 0; l < L; ++l) {
             const std::string p = v + "encoder.layers." + std::to_string(l) + ".";
             vec(p + "layer_norm1.weight"); vec(p + "layer_norm1.bias");
-            for (const char* n : {"q_proj", "k_proj", "v_proj", "out_proj"}) {
-                lin(p + "self_attn." + n + ".weight", sq[q++], D, D);
-                vec(p + "self_attn." + n + ".bias");
-            }
+            for (const char* n : {"q_proj", "k_proj", "v_proj", "out_proj"}) linear(p + "self_attn." + n, sq[q++], D, D);
             vec(p + "layer_norm2.weight"); vec(p + "layer_norm2.bias");
-            lin(p + "mlp.fc1.weight", other[o++], FF, D);
-            put(p + "mlp.fc1.bias", vecF[vf++], false, {FF});
-            lin(p + "mlp.fc2.weight", other[o++], D, FF);
-            vec(p + "mlp.fc2.bias");
+            linear(p + "mlp.fc1", other[o++], FF, D);
+            linear(p + "mlp.fc2", other[o++], D, FF);
         }
         vec(v + "post_layernorm.weight");
         vec(v + "post_layernorm.bias");
         lin("visual_projection.weight", other[o++], E, D);
+    }
+    std::vector<size_t> skipped;   // raw indices of the leaves that were set aside (mi_weights_list prints them)
+    std::vector<std::string> skipped_lines() const override {
+        std::vector<std::string> out;
+        for (size_t i : skipped) {
+            std::string l = "(set aside) " + raws[i].path + " " + raws[i].dtype + " [";
+            for (size_t j = 0; j < raws[i].shape.size(); ++j) l += (j ? "," : "") + std::to_string(raws[i].shape[j]);
+            out.push_back(l + "]");
+        }
+        return out;
     }
 
     bool has(const std::string& name) const override { return mapped.count(name) != 0; }

@@ -206,6 +206,8 @@ class ShardedTable {
     }
     uint64_t size() const { uint64_t n = 0; check(mi_knn_sharded_info(h_, &n, nullptr, nullptr, nullptr)); return n; }
     void set_option(const std::string& key, int value) { check(mi_knn_sharded_set_option(h_, key.c_str(), value)); }
+    // {searches, ncclAllGather calls, transport copies, device merges} issued so far
+    std::vector<uint64_t> stats() const { std::vector<uint64_t> v(4); check(mi_knn_sharded_stats(h_, v.data())); return v; }
     std::pair<std::vector<uint64_t>, std::vector<float>> knn(const std::vector<float>& reference, uint32_t k = 1000) const {
         std::vector<uint64_t> idx(k);
         std::vector<float> dist(k);

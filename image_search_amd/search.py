@@ -267,6 +267,12 @@ class ShardedTable:
         check(lib().mi_knn_sharded_info(self._h, ctypes.byref(rows), ctypes.byref(n), ctypes.byref(blk), ctypes.byref(tr)))
         return {"rows": rows.value, "shards": n.value, "block_rows": blk.value, "transport": self.TRANSPORTS[tr.value]}
 
+    def stats(self):
+        """what the exchange step has executed so far (mi_knn_sharded_stats)"""
+        out = (ctypes.c_uint64 * 4)()
+        check(lib().mi_knn_sharded_stats(self._h, out))
+        return dict(zip(("searches", "collectives", "copies", "merges"), (int(v) for v in out)))
+
     def __len__(self) -> int:
         return self.info()["rows"]
 

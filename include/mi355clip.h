@@ -251,8 +251,13 @@ int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint3
  * A device may be listed more than once (several shards on one GPU: how a one-GPU box tests n > 1). */
 int mi_knn_sharded_create(uint32_t dim, const int* devices, int n_dev, uint32_t block_rows, mi_knn_sharded** out);
 void mi_knn_sharded_free(mi_knn_sharded* t);
-/* any of the outputs may be NULL; transport: 0 = single shard, 1 = device-to-device / peer copies, 2 = RCCL all-gather */
+/* any of the outputs may be NULL; transport: 0 = single shard, 1 = device-to-device / peer copies, 2 = RCCL all-gather
+ * (a one-shard table made under MI_KNN_SHARDED_TRANSPORT=rccl reports 2: its one-rank communicator runs the collective) */
 int mi_knn_sharded_info(const mi_knn_sharded* t, uint64_t* rows, uint32_t* n_shards, uint32_t* block_rows, int* transport);
+/* What the exchange step of server/src/search.rs:70-86's replacement has really executed on this handle so far:
+ * out = {searches enqueued, ncclAllGather calls issued (ONE per shard and search: ids and distances travel as one packed
+ * record), transport copies issued instead, device merges}. */
+int mi_knn_sharded_stats(const mi_knn_sharded* t, uint64_t out[4]);
 int mi_knn_sharded_set_option(mi_knn_sharded* t, const char* key, int value); /* mi_knn_set_option on every shard */
 int mi_knn_sharded_reserve(mi_knn_sharded* t, uint64_t rows);
 int mi_knn_sharded_append(mi_knn_sharded* t, const float* rows, uint64_t n, uint64_t* first_id /* may be NULL */);

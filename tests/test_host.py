@@ -172,6 +172,24 @@ def test_burn_mpk_record_maps_to_the_hf_names_or_is_refused(mi, tmp_path):
     write_mpk(w, cfg, mpk, legacy=True)                                                        # {"value": [...]} records
     assert dict((n, s) for n, _, s in list_weights(mpk)) == a
 
+    # the graph the reference imports is an opset-16 export (clip/scripts/upgrade_opset.py:9-28): LayerNorm is
+    # DECOMPOSED there — gamma / beta are bare constants between Mul and Add, and the record carries scalar and integer
+    # constants that belong to no tower tensor.  Both that inventory and its un-coalesced form (MatMul + Add constants
+    # instead of Linear modules) map to the same names; what was set aside is listed, not filed under a role.
+    for kw in ({"decomposed_ln": True}, {"decomposed_ln": True, "coalesced": False}, {"coalesced": False},
+               {"decomposed_ln": True, "legacy": True}):
+        write_mpk(w, cfg, mpk, **kw)
+        got = list_weights(mpk)
+        assert dict((n, s) for n, _, s in got if not n.startswith("(set aside)")) == a, kw
+        aside = [(n, d, s) for n, d, s in got if n.startswith("(set aside)")]
+        if kw.get("decomposed_ln"):
+            # per LayerNorm two scalars, per layer the attention scale, a Reshape shape and the QuickGELU factor, once the position ids
+            assert len(aside) == 2 * (2 * cfg.layers + 2) + 3 * cfg.layers + 1, (kw, aside)
+            if not kw.get("legacy"):
+                assert sorted({d for _, d, _ in aside}) == ["F32", "I64"]
+        else:
+            assert aside == []
+
     def drop_a_bias(rec):
         rec["item"]["linear3"]["bias"] = None
     write_mpk(w, cfg, mpk, mutate=drop_a_bias)
@@ -184,6 +202,20 @@ def test_burn_mpk_record_maps_to_the_hf_names_or_is_refused(mi, tmp_path):
         rec["item"]["linear999"] = {"weight": rec["item"]["linear1"]["weight"], "bias": None}
     write_mpk(w, cfg, mpk, mutate=extra_matrix)
     assert mi.mi_weights_list(mpk.encode(), None, 0, ctypes.byref(need)) == -5
+
+    def bias_in_the_wrong_module(rec):      # a hostile permutation: one Linear's bias moved under another Linear's field
+        it = rec["item"]
+        it["linear2"]["bias2"] = it["linear3"]["bias"]
+        it["linear3"]["bias"] = None
+    write_mpk(w, cfg, mpk, mutate=bias_in_the_wrong_module, decomposed_ln=True)
+    assert mi.mi_weights_list(mpk.encode(), None, 0, ctypes.byref(need)) == -5
+
+    def a_layernorm_lost_its_beta(rec):     # decomposed form: one bare [D] constant fewer
+        it = rec["item"]
+        del it[[k for k in it if k.startswith("constant") and it[k]["param"]["shape"] == [cfg.hidden]][5]]
+    write_mpk(w, cfg, mpk, mutate=a_layernorm_lost_its_beta, decomposed_ln=True)
+    assert mi.mi_weights_list(mpk.encode(), None, 0, ctypes.byref(need)) == -5
+    assert "bare [D]-vectors" in mi.mi_last_error().decode()
     with open(mpk, "r+b") as f:
         f.truncate(1000)
     assert mi.mi_weights_list(mpk.encode(), None, 0, ctypes.byref(need)) == -2                 # MI_ERR_IO: truncated

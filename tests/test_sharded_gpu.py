@@ -2,7 +2,7 @@
 (BASELINE config 5 in miniature; the reference's one-handle shape, server/src/main.rs:30-35).
 
 A one-GPU box has one device: n > 1 shards are put on device 0 several times (the lists meet by device-to-device copies);
-the RCCL transport is exercised with its one-rank communicator.  On an 8-GPU node the same entry points
+the RCCL transport runs its collective and merge on a one-rank communicator (counted: mi_knn_sharded_stats).  On an 8-GPU node the same entry points
 take distinct devices and the all-gather runs over xGMI — unmeasured on hardware so far.
 Everything is compared bit for bit with ONE mi_knn holding every row and with the oracle."""
 import os
@@ -30,6 +30,7 @@ def test_one_shard_equals_mi_knn_search_bit_for_bit(built):
     sh = ShardedTable(768, [0])
     sh.insert_synthetic(31, 0, n)
     assert sh.info() == {"rows": n, "shards": 1, "block_rows": 4096, "transport": "single shard"}
+    assert sh.stats()["collectives"] == 0
     qs = synth.corpus_rows(32, 0, 5)
     for k in (1, 10, 100, 1000):
         assert _same(sh.knn(qs, k), one.knn(qs, k))
@@ -184,18 +185,80 @@ def test_a_live_table_changes_its_layout_device_to_device(built):
     a.close()
 
 
-def test_rccl_transport_with_its_one_rank_communicator(built, monkeypatch):
-    """The all-gather path (dlopen'ed librccl, ncclCommInitAll, ncclAllGather under a group) end to end on the
-    one device there is; with more devices only the rank count changes."""
+def test_rccl_transport_with_its_one_rank_communicator_really_issues_the_collective(built, monkeypatch):
+    """VERDICT r3 / ADVICE r3: the exchange block used to sit under `n > 1`, so this test reached dlopen +
+    ncclCommInitAll(1) and nothing else.  A table made with the RCCL transport now runs the exchange whatever its rank
+    count: ONE ncclAllGather of the packed [k x u64 | k x f32] record per shard and search (under ncclGroupStart/End, on
+    the shard's stream), then the device merge of the gathered records, then one readback — counted by the handle.
+    With more devices only the rank count changes; that run is still to come (unmeasured on > 1 GPU)."""
     monkeypatch.setenv("MI_KNN_SHARDED_TRANSPORT", "rccl")
     sh = ShardedTable(768, [0])
     monkeypatch.delenv("MI_KNN_SHARDED_TRANSPORT")
+    assert sh.info()["transport"] == "rccl all-gather"
     sh.insert_synthetic(61, 0, 10_000)
     one = EmbeddingTable(768, 0)
     one.insert_synthetic(61, 0, 10_000)
     qs = synth.corpus_rows(62, 0, 3)
-    assert _same(sh.knn(qs, 10), one.knn(qs, 10))
+    assert sh.stats() == {"searches": 0, "collectives": 0, "copies": 0, "merges": 0}
+    assert _same(sh.knn(qs, 10), one.knn(qs, 10))            # nq = 3, k = 10: record = 360 bytes -> padded to 368
+    assert sh.stats() == {"searches": 1, "collectives": 1, "copies": 0, "merges": 1}
     assert _same(sh.knn(qs[0], 1000), one.knn(qs[0], 1000))
+    assert _same(sh.knn(qs[1], 1), one.knn(qs[1], 1))        # an odd record: 12 bytes, padded to 16
+    pend = [sh.knn_async(qs[u % 3], 7) for u in range(10)]   # through the slot ring, collectives back to back
+    sh.sync()
+    for u, (gi, gd) in enumerate(pend):
+        assert _same((gi[0], gd[0]), one.knn(qs[u % 3], 7))
+    assert sh.stats() == {"searches": 13, "collectives": 13, "copies": 0, "merges": 13}
+    sh.close(); one.close()
+
+
+def test_the_copy_transport_moves_one_packed_record_per_shard(built):
+    """ids and distances of a shard's answer travel as ONE piece (they were two copies / two all-gathers per shard)."""
+    sh = ShardedTable(768, [0, 0, 0], 64)
+    sh.insert_synthetic(63, 0, 5_000)
+    one = EmbeddingTable(768, 0)
+    one.insert_synthetic(63, 0, 5_000)
+    qs = synth.corpus_rows(64, 0, 5)
+    for k in (1, 3, 10, 1000):
+        assert _same(sh.knn(qs, k), one.knn(qs, k))
+    assert sh.stats() == {"searches": 4, "collectives": 0, "copies": 12, "merges": 4}
+    single = ShardedTable(768, [0])
+    single.insert_synthetic(63, 0, 5_000)
+    assert _same(single.knn(qs, 10), one.knn(qs, 10))
+    assert single.stats() == {"searches": 1, "collectives": 0, "copies": 0, "merges": 0}   # one shard gathers nothing
+    single.close(); sh.close(); one.close()
+
+
+def test_device_append_to_an_unreserved_table_behind_a_busy_producer(built):
+    """a run of the same call landing on a shard a second time could reallocate that shard while the call's
+    earlier copies were still queued on the producer's stream (grow() only waits for EARLIER calls' work): rows lost,
+    or a freed buffer written.  Every touched shard is now grown to its final size before the first copy is enqueued.
+    More than n_shards * block rows, unreserved, behind a producer stream that is kept busy."""
+    import torch
+    n_sh, block = 3, 64
+    n = 20 * n_sh * block + 11
+    rows = synth.corpus_rows(73, 0, n)
+    producer = torch.cuda.Stream()
+    sh = ShardedTable(768, [0] * n_sh, block)
+    with torch.cuda.stream(producer):
+        d = torch.from_numpy(rows).cuda(non_blocking=True)
+        busy = torch.empty((8192, 8192), device="cuda")
+        for _ in range(30):                                 # tens of milliseconds of work in front of the copies
+            busy = torch.mm(busy.fill_(1e-3), busy)
+    assert sh.insert_device(d.data_ptr(), n, 0, producer.cuda_stream) == 0
+    more = synth.corpus_rows(74, 0, 5 * n_sh * block)
+    with torch.cuda.stream(producer):
+        d2 = torch.from_numpy(more).cuda(non_blocking=True)
+        for _ in range(10):
+            busy = torch.mm(busy.fill_(1e-3), busy)
+    assert sh.insert_device(d2.data_ptr(), len(more), 0, producer.cuda_stream) == n   # grows every shard again, copies of call 1 maybe still queued
+    allrows = np.concatenate([rows, more])
+    assert np.array_equal(sh.rows(0, len(allrows)).view(np.uint32), allrows.view(np.uint32))
+    one = EmbeddingTable(768, 0)
+    one.insert(allrows)
+    q = synth.corpus_rows(75, 0, 2)
+    assert _same(sh.knn(q, 25), one.knn(q, 25))
+    torch.cuda.synchronize()
     sh.close(); one.close()
 
 

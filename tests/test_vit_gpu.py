@@ -231,6 +231,30 @@ def test_l14_fp32_matches_golden(l14):
     m.close()
 
 
+def test_l14_fp32_batch32_is_baseline_config_2(l14):
+    """BASELINE config 2 at its own batch size: "ViT-L/14 image encoder, batch = 32 fp32, correctness vs CPU"
+    (/root/reference/server/src/clip.rs:112-124 with a chunk of 32).  M = 32 * 257 = 8 224 token rows: other tile counts
+    and another tail round than the n = 2 / n = 4 runs the fixtures cover.  Rows {0, 15, 16, 31} against the numpy
+    oracle (fp32 arithmetic, <= 1e-4), rows 0-1 against the committed transformers golden, and rows 0-1 bit-equal to
+    the n = 2 run: the fp32 GEMM's result for a row must not depend on how many rows the batch holds."""
+    cfg, w, path, u8, g = l14
+    u8_32 = synth.images_u8(int(g["image_seed"]), 32, cfg.image)
+    assert np.array_equal(u8_32[:2], u8)                       # the generator is counter-based: same first images
+    px = synth.preprocess_rgb8(u8_32)
+    m = Model.from_file(path, 0, PRECISION_F32)
+    out = m.forward(px)
+    assert out.shape == (32, 768) and np.isfinite(out).all()
+    rows = [0, 15, 16, 31]
+    ref = vit_numpy.vit_forward(w, cfg, px[rows], np.float32)
+    ok, err = close(out[rows], ref, 1e-4)
+    assert ok, err
+    ok, err = close(out[:2], g["embeds_hf_f32"], 1e-4)
+    assert ok, err
+    two = m.forward(px[:2])
+    assert np.array_equal(two.view(np.uint32), out[:2].view(np.uint32))
+    m.close()
+
+
 def test_l14_bf16_batch_and_chunking(l14, monkeypatch):
     cfg, w, path, u8, g = l14
     px = synth.preprocess_rgb8(u8)
@@ -263,17 +287,22 @@ def test_device_entry_point_matches_host_entry_point(tiny):
     m.close()
 
 
+@pytest.mark.parametrize("inventory", [{}, {"decomposed_ln": True}, {"decomposed_ln": True, "coalesced": False}],
+                         ids=["fused-ln", "decomposed-ln", "decomposed-ln-uncoalesced"])
 @pytest.mark.parametrize("prec", [PRECISION_F32, PRECISION_BF16])
-def test_model_from_burn_mpk_equals_model_from_safetensors(tiny, tmp_path, prec):
+def test_model_from_burn_mpk_equals_model_from_safetensors(tiny, tmp_path, prec, inventory):
     """Model::from_file on the kind of file `-w` names (vision_model.mpk, server/src/server_arguments.rs:8-9): the
-    same tensors through the Burn-record reader (shape-and-order mapping, Linear weights transposed back) must give
-    the very same embeddings as the safetensors file."""
+    same tensors through the Burn-record reader (shape / module / order mapping, Linear weights transposed back) must
+    give the very same embeddings as the safetensors file — for LayerNorm modules, for the DECOMPOSED LayerNorm of the
+    opset-16 graph the reference really builds (clip/scripts/upgrade_opset.py:9-28: gamma / beta as bare constants, scalar
+    and integer constants interleaved) and for that graph with MatMul + Add not coalesced into Linear modules.
+    Still parity unpinned: no file written by burn-import itself exists offline."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from make_synthetic_mpk import write_mpk
     cfg, w, path, px, g = tiny
     mpk = str(tmp_path / "vision_model.mpk")
-    write_mpk(w, cfg, mpk)
+    write_mpk(w, cfg, mpk, **inventory)
     a = Model.from_file(path, 0, prec)
     b = Model.from_file(mpk, 0, prec)
     assert (b.tokens, b.hidden, b.layers, b.ff, b.proj) == (a.tokens, a.hidden, a.layers, a.ff, a.proj)

@@ -6,6 +6,9 @@
 #include <cstdlib>
 #include "../../include/mi355clip.h"
 #include "../../image_search_amd/csrc/vit_kernels.h"
+#ifdef ATTN32_STAMPS
+#include "attn_stamps.h"   // defines the kernel's timing hooks; the library build leaves them empty
+#endif
 #include "../../image_search_amd/csrc/attn32_kernels.h"
 #include "attn64_kernels.h"
 using namespace mi;

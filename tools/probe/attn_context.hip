@@ -11,6 +11,9 @@
 #include <cstdlib>
 #include "../../include/mi355clip.h"
 #include "../../image_search_amd/csrc/vit_kernels.h"
+#ifdef ATTN32_STAMPS
+#include "attn_stamps.h"   // defines the kernel's timing hooks; the library build leaves them empty
+#endif
 #include "../../image_search_amd/csrc/attn32_kernels.h"
 using namespace mi;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
