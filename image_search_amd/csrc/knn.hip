@@ -78,16 +78,17 @@ void allow_lds(K kernel, size_t bytes) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 
+// gy > 1: a group of queries in one launch (grid.y = query, knn_kernels.h QGroup)
 template <class Top>
 void launch_scan(mi_knn* t, const float* d_q, uint32_t k, const uint64_t* lo, uint64_t* cand, uint32_t blocks,
-                 hipStream_t s, const uint32_t* run_if = nullptr) {
+                 hipStream_t s, const uint32_t* run_if = nullptr, uint32_t gy = 1, QGroup qg = QGroup{}) {
     const size_t lds = (size_t)4 * Top::LDS_KEYS * sizeof(uint64_t);
     switch (t->dim / 64) {
 #define MI_CASE(NCH)                                                                                   \
     case NCH:                                                                                          \
         allow_lds(knn_scan_kernel<NCH, Top>, lds);                                                     \
-        hipLaunchKernelGGL((knn_scan_kernel<NCH, Top>), dim3(blocks), dim3(256), lds, s, t->table,     \
-                           t->rows, d_q, k, lo, cand, (uint32_t*)nullptr, run_if);                     \
+        hipLaunchKernelGGL((knn_scan_kernel<NCH, Top>), dim3(blocks, gy), dim3(256), lds, s, t->table, \
+                           t->rows, d_q, k, lo, cand, (uint32_t*)nullptr, run_if, qg);                 \
         break;
         MI_CASE(1) MI_CASE(2) MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16)
 #undef MI_CASE
@@ -98,26 +99,29 @@ void launch_scan(mi_knn* t, const float* d_q, uint32_t k, const uint64_t* lo, ui
 
 template <class Top>
 void launch_merge(const uint64_t* in, uint32_t n_lists, uint32_t k, uint32_t lpb, uint64_t* out, uint32_t nq,
-                  size_t in_stride, size_t out_stride, hipStream_t s, const uint32_t* run_if = nullptr) {
+                  size_t in_stride, size_t out_stride, hipStream_t s, const uint32_t* run_if = nullptr, uint32_t run_stride = 0) {
     const size_t lds = (size_t)4 * Top::LDS_KEYS * sizeof(uint64_t);
     allow_lds(knn_merge_kernel<Top>, lds + 4096);
     const uint32_t blocks = (n_lists + lpb - 1) / lpb;
     hipLaunchKernelGGL((knn_merge_kernel<Top>), dim3(blocks, nq), dim3(256), lds, s, in, n_lists, k, lpb, out,
-                       in_stride, out_stride, run_if);
+                       in_stride, out_stride, run_if, run_stride);
     HIP_CHECK(hipGetLastError());
 }
 
 // One pass: the kp <= 1024 smallest keys (> *lo if lo) of the shard, ascending, into keys_out[0..kp).
+// gy > 1 (register lists only): the same pass for a group of gy queries (contiguous at d_q) in the same launches, query y
+// gated by run_if[y * qg.flags], its keys to keys_out + y * qg.out
 template <class Top>
 void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint64_t* keys_out, hipStream_t s,
-              const uint32_t* run_if = nullptr) {
+              const uint32_t* run_if = nullptr, uint32_t gy = 1, QGroup qg = QGroup{}) {
     const uint32_t bpc = Top::LDS_KEYS == 0 ? 4 : (Top::KP <= 256 ? 4 : 2);
     const uint64_t n_tiles = (t->rows + 63) / 64;
     uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * bpc, (n_tiles + 3) / 4);
     blocks = std::max(blocks, 1u);
     const uint32_t lists = blocks * 4;
-    ensure(t, (void**)&t->d_cand, &t->cand_keys, (size_t)lists * kp, sizeof(uint64_t));
-    launch_scan<Top>(t, d_q, kp, lo, t->d_cand, blocks, s, run_if);
+    ensure(t, (void**)&t->d_cand, &t->cand_keys, (size_t)lists * kp * gy, sizeof(uint64_t));
+    qg.lists = (uint64_t)lists * kp;
+    launch_scan<Top>(t, d_q, kp, lo, t->d_cand, blocks, s, run_if, gy, qg);
     if constexpr (Top::LDS_KEYS != 0) {
         // k > 64: block-cooperative tree, 16 lists per block per level, ping-pong between d_tmp halves
         constexpr uint32_t LPB = 16;
@@ -136,12 +140,12 @@ void one_pass(mi_knn* t, const float* d_q, uint32_t kp, const uint64_t* lo, uint
     }
     // tree: <= 64 lists per block, then one block
     if (lists <= 64) {
-        launch_merge<Top>(t->d_cand, lists, kp, lists, keys_out, 1, 0, 0, s, run_if);
+        launch_merge<Top>(t->d_cand, lists, kp, lists, keys_out, gy, qg.lists, qg.out, s, run_if, qg.flags);
     } else {
         const uint32_t lpb = 32, mid = (lists + lpb - 1) / lpb;
-        ensure(t, (void**)&t->d_tmp, &t->tmp_keys, (size_t)mid * kp, sizeof(uint64_t));
-        launch_merge<Top>(t->d_cand, lists, kp, lpb, t->d_tmp, 1, 0, 0, s, run_if);
-        launch_merge<Top>(t->d_tmp, mid, kp, mid, keys_out, 1, 0, 0, s, run_if);
+        ensure(t, (void**)&t->d_tmp, &t->tmp_keys, (size_t)mid * kp * gy, sizeof(uint64_t));
+        launch_merge<Top>(t->d_cand, lists, kp, lpb, t->d_tmp, gy, qg.lists, (size_t)mid * kp, s, run_if, qg.flags);
+        launch_merge<Top>(t->d_tmp, mid, kp, mid, keys_out, gy, (size_t)mid * kp, qg.out, s, run_if, qg.flags);
     }
 }
 
@@ -154,9 +158,6 @@ bool prefilter_applies(const mi_knn* t, uint32_t k) {
     const uint32_t width = t->prefilter == 2 ? 256u : 128u;  // whole 256-byte chunks per mirror row
     return t->prefilter && (k <= 64 || (k <= 4096 && t->select_path)) && t->dim % width == 0 && t->rows >= PREF_MIN_ROWS;
 }
-// nq_batch = 4 or 8 (byte mirror, dim 768): query qi of a batch whose stage-1 keys come from ONE pass over the mirror —
-// the call for qi == 0 (d_q = the first of the nq_batch queries, contiguous) also runs that pass; every call runs its own
-// query's selects, collect and stage 2 on the shared workspace (stream order keeps the queries apart).
 template <int NCH>
 void launch_coarse8_batched(mi_knn* t, const uint8_t* m8, const float* d_q, float e0, uint32_t nq, uint32_t blocks, hipStream_t s) {
     if constexpr (NCH == 12) {  // built for dim 768, the width of the reference's table (server/src/clip.rs:140-143)
@@ -173,13 +174,27 @@ void launch_coarse8_batched(mi_knn* t, const uint8_t* m8, const float* d_q, floa
         fail(MI_ERR_UNSUPPORTED, "the batched two-stage search is built for dim 768");
     }
 }
-uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s, uint32_t nq_batch = 0, uint32_t qi = 0) {
-    ensure(t, (void**)&t->d_keys32, &t->keys32_cap, (size_t)t->cap * std::max(1u, nq_batch), sizeof(uint32_t));
-    ensure(t, (void**)&t->d_sel, &t->sel_cap, (size_t)6 * SEL_BINS + 64, sizeof(uint32_t));
-    ensure(t, (void**)&t->d_cand, &t->cand_keys, (size_t)4096, sizeof(uint64_t));
-    ensure(t, (void**)&t->d_pref_rows, &t->pref_rows_cap, (size_t)2 * PREF_CAP, sizeof(uint32_t));  // rows, then their exact keys
-    ensure(t, (void**)&t->d_pref_keys, &t->pref_keys_cap, (size_t)4096, sizeof(uint64_t));
-    ensure(t, (void**)&t->d_pref_flag, &t->pref_flag_cap, (size_t)4, sizeof(uint32_t));
+// the strides of a group of gy queries on the shard's workspaces (every per-query buffer holds gy copies back to back)
+constexpr uint32_t SEL_WORDS = 6 * SEL_BINS + 64;
+QGroup group_of(const mi_knn* t, uint32_t gy) {
+    QGroup g;
+    if (gy <= 1) return g;
+    g.q = t->dim; g.keys = t->cap; g.sel = SEL_WORDS; g.flags = 4; g.rows = (uint64_t)2 * PREF_CAP; g.coll = 4096; g.out = 4096; g.rho = 1;
+    return g;
+}
+// nq_batch = 2, 4 or 8 (byte mirror, dim 768): a GROUP of queries, contiguous at d_q: one pass over the mirror writes the
+// stage-1 keys of all of them, and every later kernel of the search — the selects, the collect, stage 2, the select over the
+// candidates, the sort — runs ONCE for the group with the query as grid.y on per-query copies of the workspaces (QGroup).
+// Returns the fallback word of query 0 (query y: + 4 y).
+uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s, uint32_t nq_batch = 0) {
+    const uint32_t gy = std::max(1u, nq_batch);
+    const QGroup qg = group_of(t, gy);
+    ensure(t, (void**)&t->d_keys32, &t->keys32_cap, (size_t)t->cap * gy, sizeof(uint32_t));
+    ensure(t, (void**)&t->d_sel, &t->sel_cap, (size_t)SEL_WORDS * gy, sizeof(uint32_t));
+    ensure(t, (void**)&t->d_cand, &t->cand_keys, (size_t)4096 * gy, sizeof(uint64_t));
+    ensure(t, (void**)&t->d_pref_rows, &t->pref_rows_cap, (size_t)2 * PREF_CAP * gy, sizeof(uint32_t));  // rows, then their exact keys
+    ensure(t, (void**)&t->d_pref_keys, &t->pref_keys_cap, (size_t)4096 * gy, sizeof(uint64_t));
+    ensure(t, (void**)&t->d_pref_flag, &t->pref_flag_cap, (size_t)4 * gy, sizeof(uint32_t));
     const bool bytes = t->prefilter == 2;
     const size_t mirror_elems = bytes ? ((size_t)t->cap * t->dim + 1) / 2 : (size_t)t->cap * t->dim;  // in uint16 units
     t->mirror_rows = std::min(t->mirror_rows, t->rows);
@@ -212,15 +227,15 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s,
     uint32_t* key32 = t->d_pref_rows + PREF_CAP;
     uint32_t* count2 = t->d_sel + 6 * SEL_BINS;
     SelState* states = reinterpret_cast<SelState*>(t->d_sel + 6 * SEL_BINS + 4);
-    const size_t sel_bytes = ((size_t)6 * SEL_BINS + 64) * sizeof(uint32_t);
+    const size_t sel_bytes = (size_t)SEL_WORDS * gy * sizeof(uint32_t);
     HIP_CHECK(hipMemsetAsync(t->d_sel, 0, sel_bytes, s));
-    HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), s));
+    HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)4 * gy * sizeof(uint32_t), s));
     static const uint32_t ring8_bpc = [] { const char* e = std::getenv("MI_KNN_RING_BPC"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 2u; }();  // A/B
     const float e0 = 4.1f * (float)(t->dim + 8) * 0x1p-24f + 2e-6f;  // fp32 summations, norms, divisions
     const float eps = 0x1p-8f + e0;                                  // bf16: 8 significant bits, unit roundoff 2^-8
     if (bytes) {
         uint8_t* m8 = reinterpret_cast<uint8_t*>(t->d_mirror);
-        const uint32_t* keys_q = t->d_keys32 + (size_t)qi * t->cap;
+        const uint32_t* keys_q = t->d_keys32;   // query y: + y * cap (QGroup)
         switch (t->dim / 64) {
 #define MI_CASE(NCH)                                                                                                     \
     case NCH:                                                                                                            \
@@ -237,14 +252,15 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s,
         else if (nq_batch == 0)                                                                                          \
             hipLaunchKernelGGL((knn_scan_coarse8_kernel<NCH, 4>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8, \
                                t->d_cfac8, t->d_g8, t->rows, d_q, e0, t->d_keys32, t->d_rho8);                           \
-        else if (qi == 0)                                                                                                \
+        else                                                                                                             \
             launch_coarse8_batched<NCH>(t, m8, d_q, e0, nq_batch, blocks, s);                                            \
         for (int p = 0; p < 3; ++p)                                                                                      \
-            hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb), dim3(256), 0, s, keys_q, t->rows, k, p, t->d_sel, states); \
-        hipLaunchKernelGGL(knn_prefilter_collect8_kernel, dim3(hb), dim3(256), 0, s, keys_q, t->d_cfac8, t->rows, k,     \
-                           t->d_sel, states, t->d_rho8 + qi, e0, PREF_CAP, t->d_pref_rows, flags);                       \
-        hipLaunchKernelGGL((knn_rescore_kernel<NCH>), dim3(t->n_cu * 8), dim3(256), 0, s, t->table, d_q, t->d_pref_rows, \
-                           flags, PREF_CAP, key32);                                                                      \
+            hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb, gy), dim3(256), 0, s, keys_q, t->rows, k, p, t->d_sel, states, \
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, qg, 0);     \
+        hipLaunchKernelGGL(knn_prefilter_collect8_kernel, dim3(hb, gy), dim3(256), 0, s, keys_q, t->d_cfac8, t->rows, k, \
+                           t->d_sel, states, t->d_rho8, e0, PREF_CAP, t->d_pref_rows, flags, qg);                        \
+        hipLaunchKernelGGL((knn_rescore_kernel<NCH>), dim3(t->n_cu * (gy > 1 ? 2 : 8), gy), dim3(256), 0, s, t->table, d_q, \
+                           t->d_pref_rows, flags, PREF_CAP, key32, qg);                                                  \
         break;
             MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16)
 #undef MI_CASE
@@ -279,29 +295,31 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s,
     const uint32_t* go = flags + 2;
     const uint32_t cb = (uint32_t)t->n_cu * 2;
     for (int p = 0; p < 6; ++p)
-        hipLaunchKernelGGL(knn_select_hist_kernel, dim3(cb), dim3(256), 0, s, key32, (uint64_t)PREF_CAP, k, p, t->d_sel, states, go, flags,
-                           t->d_pref_rows);
-    hipLaunchKernelGGL(knn_select_collect_kernel, dim3(cb), dim3(256), 0, s, key32, (uint64_t)PREF_CAP, k, t->d_sel, states, t->d_cand, count2,
-                       go, flags, t->d_pref_rows);
-    hipLaunchKernelGGL(knn_select_sort_kernel, dim3(1), dim3(1024), 0, s, t->d_cand, count2, k, t->d_pref_keys, go);
+        hipLaunchKernelGGL(knn_select_hist_kernel, dim3(cb, gy), dim3(256), 0, s, key32, (uint64_t)PREF_CAP, k, p, t->d_sel, states, go, flags,
+                           t->d_pref_rows, qg, 1);
+    hipLaunchKernelGGL(knn_select_collect_kernel, dim3(cb, gy), dim3(256), 0, s, key32, (uint64_t)PREF_CAP, k, t->d_sel, states, t->d_cand, count2,
+                       go, flags, t->d_pref_rows, qg, 1);
+    hipLaunchKernelGGL(knn_select_sort_kernel, dim3(1, gy), dim3(1024), 0, s, t->d_cand, count2, k, t->d_pref_keys, go, qg);
     HIP_CHECK(hipGetLastError());
     return flags + 1;
 }
 
 // 64 < k <= 4096: every row's distance key, then the k smallest (distance, id) keys by radix select (knn_kernels.h)
-void select_pass(mi_knn* t, const float* d_q, uint32_t k, uint64_t* keys_out, hipStream_t s, const uint32_t* run_if = nullptr) {
+// gy > 1: a group of gy queries (contiguous at d_q) in the same launches: query y gated by run_if[4 y], keys to keys_out + 4096 y
+void select_pass(mi_knn* t, const float* d_q, uint32_t k, uint64_t* keys_out, hipStream_t s, const uint32_t* run_if = nullptr, uint32_t gy = 1) {
+    const QGroup qg = group_of(t, gy);
     const uint64_t n_tiles = (t->rows + 63) / 64;
     uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 4, (n_tiles + 3) / 4);
     blocks = std::max(blocks, 1u);
-    ensure(t, (void**)&t->d_keys32, &t->keys32_cap, (size_t)t->cap, sizeof(uint32_t));
-    ensure(t, (void**)&t->d_sel, &t->sel_cap, (size_t)6 * SEL_BINS + 64, sizeof(uint32_t));
-    ensure(t, (void**)&t->d_cand, &t->cand_keys, (size_t)4096, sizeof(uint64_t));
-    HIP_CHECK(hipMemsetAsync(t->d_sel, 0, ((size_t)6 * SEL_BINS + 64) * sizeof(uint32_t), s));
+    ensure(t, (void**)&t->d_keys32, &t->keys32_cap, (size_t)t->cap * gy, sizeof(uint32_t));
+    ensure(t, (void**)&t->d_sel, &t->sel_cap, (size_t)SEL_WORDS * gy, sizeof(uint32_t));
+    ensure(t, (void**)&t->d_cand, &t->cand_keys, (size_t)4096 * gy, sizeof(uint64_t));
+    HIP_CHECK(hipMemsetAsync(t->d_sel, 0, (size_t)SEL_WORDS * gy * sizeof(uint32_t), s));
     switch (t->dim / 64) {
 #define MI_CASE(NCH)                                                                                          \
     case NCH:                                                                                                 \
-        hipLaunchKernelGGL((knn_scan_kernel<NCH, WaveTopReg, 1>), dim3(blocks), dim3(256), 0, s, t->table, t->rows, d_q, k, \
-                           (const uint64_t*)nullptr, (uint64_t*)nullptr, t->d_keys32, run_if);                \
+        hipLaunchKernelGGL((knn_scan_kernel<NCH, WaveTopReg, 1>), dim3(blocks, gy), dim3(256), 0, s, t->table, t->rows, d_q, k, \
+                           (const uint64_t*)nullptr, (uint64_t*)nullptr, t->d_keys32, run_if, qg);            \
         break;
         MI_CASE(1) MI_CASE(2) MI_CASE(4) MI_CASE(8) MI_CASE(12) MI_CASE(16)
 #undef MI_CASE
@@ -312,9 +330,11 @@ void select_pass(mi_knn* t, const float* d_q, uint32_t k, uint64_t* keys_out, hi
     uint32_t* count = t->d_sel + 6 * SEL_BINS;
     SelState* states = reinterpret_cast<SelState*>(t->d_sel + 6 * SEL_BINS + 4);  // 6 states of 24 bytes behind the counter
     for (int p = 0; p < 6; ++p)
-        hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, p, t->d_sel, states, run_if);
-    hipLaunchKernelGGL(knn_select_collect_kernel, dim3(hb), dim3(256), 0, s, t->d_keys32, t->rows, k, t->d_sel, states, t->d_cand, count, run_if);
-    hipLaunchKernelGGL(knn_select_sort_kernel, dim3(1), dim3(1024), 0, s, t->d_cand, count, k, keys_out, run_if);
+        hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb, gy), dim3(256), 0, s, t->d_keys32, t->rows, k, p, t->d_sel, states, run_if,
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, qg, 0);
+    hipLaunchKernelGGL(knn_select_collect_kernel, dim3(hb, gy), dim3(256), 0, s, t->d_keys32, t->rows, k, t->d_sel, states, t->d_cand, count, run_if,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, qg, 0);
+    hipLaunchKernelGGL(knn_select_sort_kernel, dim3(1, gy), dim3(1024), 0, s, t->d_cand, count, k, keys_out, run_if, qg);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -378,35 +398,37 @@ uint32_t reg_pass_lists(const mi_knn* t) {
     return 4 * std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 4, (n_tiles + 3) / 4));
 }
 
-// one query through the two stages (d_keys sized by the caller); nq_batch / qi: prefilter_pass
-void two_stage_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s, uint32_t nq_batch, uint32_t qi) {
+// One query (nq_batch = 0) or a group of nq_batch queries, contiguous at d_q, through the two stages; results to
+// d_idx / d_dist [nq][k].  d_keys is sized by the caller (4096 keys per query).
+void two_stage(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s, uint32_t nq_batch) {
+    const uint32_t gy = std::max(1u, nq_batch);
+    const QGroup qg = group_of(t, gy);
     // every workspace of this search at its final size BEFORE the first launch: growing one later would free a buffer
     // that kernels already queued on `s` still use (ensure() only waits for EARLIER searches)
     if (k <= 64) {
         const uint32_t lists = reg_pass_lists(t);
-        ensure(t, (void**)&t->d_cand, &t->cand_keys, std::max<size_t>(4096, (size_t)lists * k), sizeof(uint64_t));
-        if (lists > 64) ensure(t, (void**)&t->d_tmp, &t->tmp_keys, (size_t)((lists + 31) / 32) * k, sizeof(uint64_t));
+        ensure(t, (void**)&t->d_cand, &t->cand_keys, std::max<size_t>((size_t)4096 * gy, (size_t)lists * k * gy), sizeof(uint64_t));
+        if (lists > 64) ensure(t, (void**)&t->d_tmp, &t->tmp_keys, (size_t)((lists + 31) / 32) * k * gy, sizeof(uint64_t));
     }
-    const uint32_t* fallback = prefilter_pass(t, d_q, k, s, nq_batch, qi);
-    // the single pass, every kernel of it returning at once unless *fallback
-    if (k <= 64) one_pass<WaveTopReg>(t, d_q, k, nullptr, t->d_keys, s, fallback);
-    else select_pass(t, d_q, k, t->d_keys, s, fallback);
-    hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, s, t->d_keys, k, id_map(t),
-                       d_idx, d_dist, (size_t)0, (size_t)0, t->d_pref_keys, fallback);
+    const uint32_t* fallback = prefilter_pass(t, d_q, k, s, nq_batch);
+    // the single pass, every kernel of it returning at once unless the query's fallback word is set
+    if (k <= 64) one_pass<WaveTopReg>(t, d_q, k, nullptr, t->d_keys, s, fallback, gy, qg);
+    else select_pass(t, d_q, k, t->d_keys, s, fallback, gy);
+    hipLaunchKernelGGL(knn_finalize_kernel, dim3((k + 255) / 256, gy), dim3(256), 0, s, t->d_keys, k, id_map(t),
+                       d_idx, d_dist, (size_t)qg.out, (size_t)(gy > 1 ? k : 0), t->d_pref_keys, fallback, qg.flags);
     HIP_CHECK(hipGetLastError());
 }
 
-// nq = 2, 4 or 8 queries (contiguous at d_q) through the two stages with ONE pass over the byte mirror; bit-identical to nq
-// single searches (the per-(row, query) arithmetic of stage 1 is the single kernel's; stage 2 is the single search's own)
+// nq = 2, 4 or 8 queries (contiguous at d_q) through the two stages with ONE pass over the byte mirror and ONE launch of
+// every later kernel for the whole group (grid.y = query); bit-identical to nq single searches (the per-(row, query)
+// arithmetic of stage 1 is the single kernel's; the selects and stage 2 are the single search's own kernels)
 bool batched_two_stage_applies(const mi_knn* t, uint32_t k) {
     return t->prefilter == 2 && t->dim == 768 && prefilter_applies(t, k) && !(t->pref_adaptive && (t->pref_skip_left || t->pref_probing));
 }
 void search_batched_two_stage(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
-    const uint32_t passes = (k + 1023) / 1024;
-    ensure(t, (void**)&t->d_keys, &t->keys_cap, (size_t)std::max<uint32_t>(passes * 1024, 4096), sizeof(uint64_t));
+    ensure(t, (void**)&t->d_keys, &t->keys_cap, (size_t)4096 * nq, sizeof(uint64_t));
     t->last_prefiltered = true;
-    for (uint32_t qi = 0; qi < nq; ++qi)
-        two_stage_one(t, d_q + (size_t)qi * t->dim, k, d_idx + (size_t)qi * k, d_dist + (size_t)qi * k, s, nq, qi);
+    two_stage(t, d_q, k, d_idx, d_dist, s, nq);
 }
 
 void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
@@ -431,7 +453,7 @@ void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float*
         }
     }
     if (t->last_prefiltered) {
-        two_stage_one(t, d_q, k, d_idx, d_dist, s, 0, 0);
+        two_stage(t, d_q, k, d_idx, d_dist, s, 0);
         if (t->pref_adaptive) pref_record(t, s);
         return;
     }
@@ -584,8 +606,9 @@ int mi_knn_set_option(mi_knn* t, const char* key, int value) {
             if (value != t->prefilter) pref_reset(t);
             t->prefilter = value;
         } else if (k == "prefilter_adaptive") {
-            // 1 (default): a corpus that makes the two-stage search fall back twice in a row (or keeps > 2^20 candidates per
-            // query) is served by the single pass alone for the next 64 queries, then probed again; 0: every query tries stage 1
+            // 1 (default): a corpus that makes the two-stage search FALL BACK twice in a row is served by the single pass alone
+            // for the next 64 single-query searches, then probed again with two queries (only fallbacks count: the candidate
+            // count does not, pref_fold); 0: every query tries stage 1
             pref_reset(t);
             t->pref_adaptive = value != 0;
         } else {

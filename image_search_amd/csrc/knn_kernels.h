@@ -208,6 +208,21 @@ struct RowAcc {
     __device__ __forceinline__ float sumsq() const { return row16_sum((s0 + s1) + (s2 + s3)); }
 };
 
+// A group of queries that share their launches (the batched two-stage search): query y = blockIdx.y of a kernel works on
+// its OWN copy of every per-query buffer, found at base + y * stride.  Strides in elements of the buffer's type; all
+// zero (and gridDim.y == 1) for a single query, which is then exactly the code that ran before the groups existed.
+struct QGroup {
+    uint32_t q = 0;       // query vectors (floats)
+    uint64_t keys = 0;    // one 32-bit distance key per table row (u32)
+    uint32_t sel = 0;     // histograms + SelState words + the collect counter (u32)
+    uint32_t flags = 0;   // {candidate count, fallback, go, -} (u32)
+    uint64_t rows = 0;    // candidate rows, then their exact keys (u32)
+    uint32_t coll = 0;    // keys collected by a select (u64)
+    uint32_t out = 0;     // sorted result keys (u64)
+    uint64_t lists = 0;   // per-wave lists of the register-path scan (u64)
+    uint32_t rho = 0;     // per-query scalars (floats)
+};
+
 // grid: any number of 256-thread blocks; wave w of the grid takes tiles w, w+W, ...
 // cand: [gridDim.x*4][k] keys out.  lo_ptr (nullable): keys <= *lo_ptr are skipped
 // (used when k > 1024 is served in several passes).
@@ -220,9 +235,14 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const float* __restric
                                                        const uint64_t* __restrict__ lo_ptr,
                                                        uint64_t* __restrict__ cand,
                                                        uint32_t* __restrict__ all_keys = nullptr,
-                                                       const uint32_t* __restrict__ run_if = nullptr) {
+                                                       const uint32_t* __restrict__ run_if = nullptr, QGroup qg = QGroup{}) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int DIM = NCH * 64;
+    // query blockIdx.y of a group that shares this launch (QGroup: all strides 0 for a single query)
+    q += (size_t)blockIdx.y * qg.q;
+    if (cand) cand += (size_t)blockIdx.y * qg.lists;
+    if (all_keys) all_keys += (size_t)blockIdx.y * qg.keys;
+    if (run_if) run_if += (size_t)blockIdx.y * qg.flags;
     if (run_if && *run_if == 0u) return;  // the fallback behind a prefilter that did not need it
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -356,8 +376,16 @@ __global__ __launch_bounds__(256) void knn_select_hist_kernel(const uint32_t* __
                                                               int p, uint32_t* __restrict__ hist, SelState* __restrict__ states,
                                                               const uint32_t* __restrict__ run_if = nullptr,
                                                               const uint32_t* __restrict__ n_dev = nullptr,
-                                                              const uint32_t* __restrict__ row_of = nullptr) {
+                                                              const uint32_t* __restrict__ row_of = nullptr, QGroup qg = QGroup{},
+                                                              int keys_are_rows = 0) {
     __shared__ uint32_t lh[SEL_BINS];
+    // query blockIdx.y of a group (QGroup); keys_are_rows: `keys` are the candidates' exact keys (they live behind the rows)
+    keys += (size_t)blockIdx.y * (keys_are_rows ? qg.rows : qg.keys);
+    hist += (size_t)blockIdx.y * qg.sel;
+    states = reinterpret_cast<SelState*>(reinterpret_cast<uint32_t*>(states) + (size_t)blockIdx.y * qg.sel);
+    if (run_if) run_if += (size_t)blockIdx.y * qg.flags;
+    if (n_dev) n_dev += (size_t)blockIdx.y * qg.flags;
+    if (row_of) row_of += (size_t)blockIdx.y * qg.rows;
     if (run_if && *run_if == 0u) return;
     if (n_dev) n_rows = min(n_rows, (uint64_t)*n_dev);
     const SelState st = sel_advance(hist, states, p, k, n_rows);
@@ -413,7 +441,16 @@ __global__ __launch_bounds__(256) void knn_select_collect_kernel(const uint32_t*
                                                                  uint64_t* __restrict__ out, uint32_t* __restrict__ count,
                                                                  const uint32_t* __restrict__ run_if = nullptr,
                                                                  const uint32_t* __restrict__ n_dev = nullptr,
-                                                                 const uint32_t* __restrict__ row_of = nullptr) {
+                                                                 const uint32_t* __restrict__ row_of = nullptr, QGroup qg = QGroup{},
+                                                                 int keys_are_rows = 0) {
+    keys += (size_t)blockIdx.y * (keys_are_rows ? qg.rows : qg.keys);
+    hist += (size_t)blockIdx.y * qg.sel;
+    states = reinterpret_cast<SelState*>(reinterpret_cast<uint32_t*>(states) + (size_t)blockIdx.y * qg.sel);
+    out += (size_t)blockIdx.y * qg.coll;
+    count += (size_t)blockIdx.y * qg.sel;   // the counter lives in the select block
+    if (run_if) run_if += (size_t)blockIdx.y * qg.flags;
+    if (n_dev) n_dev += (size_t)blockIdx.y * qg.flags;
+    if (row_of) row_of += (size_t)blockIdx.y * qg.rows;
     if (run_if && *run_if == 0u) return;
     if (n_dev) n_rows = min(n_rows, (uint64_t)*n_dev);
     const SelState st = sel_advance(hist, states, 6, k, n_rows);
@@ -433,8 +470,12 @@ __global__ __launch_bounds__(256) void knn_select_collect_kernel(const uint32_t*
 // one block: the (<= 4096) collected keys ascending into out[0, k), KEY_MAX behind them
 __global__ __launch_bounds__(1024) void knn_select_sort_kernel(const uint64_t* __restrict__ in, const uint32_t* __restrict__ count,
                                                                uint32_t k, uint64_t* __restrict__ out,
-                                                               const uint32_t* __restrict__ run_if = nullptr) {
+                                                               const uint32_t* __restrict__ run_if = nullptr, QGroup qg = QGroup{}) {
     __shared__ uint64_t buf[4096];
+    in += (size_t)blockIdx.y * qg.coll;
+    count += (size_t)blockIdx.y * qg.sel;
+    out += (size_t)blockIdx.y * qg.out;
+    if (run_if) run_if += (size_t)blockIdx.y * qg.flags;
     if (run_if && *run_if == 0u) return;
     const uint32_t n = min(*count, k);
     int np = 64;
@@ -900,7 +941,13 @@ __global__ __launch_bounds__(256) void knn_prefilter_collect8_kernel(const uint3
                                                                      uint64_t n_rows, uint32_t k, const uint32_t* __restrict__ hist,
                                                                      SelState* __restrict__ states, const float* __restrict__ rho_ptr,
                                                                      float e0, uint32_t cap, uint32_t* __restrict__ cand_rows,
-                                                                     uint32_t* __restrict__ count) {
+                                                                     uint32_t* __restrict__ count, QGroup qg = QGroup{}) {
+    keys += (size_t)blockIdx.y * qg.keys;
+    hist += (size_t)blockIdx.y * qg.sel;
+    states = reinterpret_cast<SelState*>(reinterpret_cast<uint32_t*>(states) + (size_t)blockIdx.y * qg.sel);
+    rho_ptr += (size_t)blockIdx.y * qg.rho;
+    cand_rows += (size_t)blockIdx.y * qg.rows;
+    count += (size_t)blockIdx.y * qg.flags;
     const SelState st = sel_advance(hist, states, 3, k, n_rows);
     float tau = __uint_as_float(0x7F800000u);  // fewer rows than k, or a NaN at rank k: everything
     if (n_rows >= k && st.fixed >= 1) {
@@ -937,8 +984,12 @@ __global__ __launch_bounds__(256) void knn_prefilter_collect8_kernel(const uint3
 template <int NCH>
 __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restrict__ table, const float* __restrict__ q,
                                                           const uint32_t* __restrict__ cand_rows, uint32_t* __restrict__ flags,
-                                                          uint32_t cap, uint32_t* __restrict__ key32_out) {
+                                                          uint32_t cap, uint32_t* __restrict__ key32_out, QGroup qg = QGroup{}) {
     constexpr int DIM = NCH * 64;
+    q += (size_t)blockIdx.y * qg.q;
+    cand_rows += (size_t)blockIdx.y * qg.rows;
+    key32_out += (size_t)blockIdx.y * qg.rows;
+    flags += (size_t)blockIdx.y * qg.flags;
     const uint32_t C = flags[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         flags[1] = C > cap ? 1u : 0u;
@@ -1053,9 +1104,10 @@ template <class Top>
 __global__ __launch_bounds__(256) void knn_merge_kernel(const uint64_t* __restrict__ in, uint32_t n_lists,
                                                         uint32_t k, uint32_t lpb, uint64_t* __restrict__ out,
                                                         size_t in_stride, size_t out_stride,
-                                                        const uint32_t* __restrict__ run_if = nullptr) {
+                                                        const uint32_t* __restrict__ run_if = nullptr, uint32_t run_stride = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint64_t wave_best[4][64];  // register form hands its lists over through here
+    if (run_if) run_if += (size_t)blockIdx.y * run_stride;
     if (run_if && *run_if == 0u) return;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     in += blockIdx.y * in_stride;
@@ -1181,9 +1233,10 @@ __global__ void knn_finalize_kernel(const uint64_t* __restrict__ keys, uint32_t 
                                     uint64_t* __restrict__ idx, float* __restrict__ dist,
                                     size_t key_stride, size_t out_stride,
                                     const uint64_t* __restrict__ prefilter_keys = nullptr,
-                                    const uint32_t* __restrict__ fallback = nullptr) {
+                                    const uint32_t* __restrict__ fallback = nullptr, uint32_t fallback_stride = 0) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
+    if (fallback) fallback += (size_t)blockIdx.y * fallback_stride;
     if (fallback && *fallback == 0u) keys = prefilter_keys;
     const uint64_t key = keys ? keys[blockIdx.y * key_stride + j] : KEY_MAX;
     uint64_t* oi = idx + blockIdx.y * out_stride;

@@ -187,7 +187,7 @@ int mi_knn_set_option(mi_knn* t, const char* key, int value);
 /* Of the most recent single-query search of this shard (waits for it): how many rows stage 2 re-evaluated, and whether the
  * single pass had to answer instead (then `candidates` is the count that did not fit).  Both 0 when the search did not
  * go through the prefilter (option off, k > 4096, fewer than 2^18 rows, stage 1 switched off for the moment by the adaptive
- * rule).  Behind a batched call: of its last query. */
+ * rule).  Behind a batched call: of the FIRST query of its last group. */
 int mi_knn_prefilter_stats(mi_knn* t, uint32_t* candidates, uint32_t* fell_back);
 /* The adaptive state (waits for the searches in flight): out = {searches for which stage 1 is still switched off,
  * consecutive fallbacks seen, searches that skipped stage 1 so far, rows the table held when the byte mirror's channel

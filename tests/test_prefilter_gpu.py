@@ -419,8 +419,10 @@ def test_a_growing_table_keeps_its_mirror_and_refreshes_the_channel_scales_at_4x
 @pytest.mark.parametrize("k", [1, 10, 64, 1000])
 def test_batched_queries_share_one_pass_over_the_byte_mirror(built, k):
     """mi_knn_search with nq > 1 and mi_knn_search_batched_device used to bypass the prefilter.  With the
-    byte mirror 8, 4 or 2 queries now share ONE stage-1 pass (knn_scan_coarse8_batched_kernel: a query per 16-lane group,
-    rows handed round by ds_bpermute), each followed by its own stage 2: ids and distance bits of nq single searches."""
+    byte mirror 8, 4 or 2 queries now share ONE stage-1 pass (knn_scan_coarse8_batched_kernel: a query per 16-lane group)
+    and, since round 4, ONE launch of every later kernel — selects, collect, stage 2, select over the candidates, sort,
+    the gated single pass, finalize — with the query as grid.y on per-query workspaces (QGroup): ids and distance bits of nq
+    single searches."""
     import torch
     t = EmbeddingTable(DIM, 0)
     t.insert_synthetic(31, 0, N + 1234)                         # a ragged last tile
@@ -446,4 +448,42 @@ def test_batched_queries_share_one_pass_over_the_byte_mirror(built, k):
         torch.cuda.synchronize()
         assert np.array_equal(d_i.cpu().numpy()[:nq].view(np.uint64), want[0][:nq])
         assert np.array_equal(d_d.cpu().numpy()[:nq].view(np.uint32), want[1][:nq].view(np.uint32))
+    t.close()
+
+
+@pytest.mark.parametrize("k", [10, 1000])
+def test_a_group_in_which_some_queries_fall_back_and_others_do_not(built, k):
+    """The queries of a group share every launch, the gated single pass included: query y of the group runs it iff ITS OWN
+    fallback word is set.  4.3 M duplicates of one row + 300 k random rows; queries beside the duplicated row collect more
+    than 2^22 candidates (fallback), random queries a few hundred (no fallback) — mixed inside one group of 8, a group of
+    4 and a group of 2, every answer equal to the single pass bit for bit."""
+    import torch
+    gen = torch.Generator(device="cuda"); gen.manual_seed(12)
+    base = torch.randn((DIM,), device="cuda", generator=gen)
+    t = EmbeddingTable(DIM, 0)
+    t.reserve(4_600_000)
+    t.insert_synthetic(33, 0, N)
+    x = base[None, :].repeat(100_000, 1).contiguous()
+    for i in range(43):
+        t.insert_device(x.data_ptr(), 100_000, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    near = lambda: (base + 0.01 * torch.randn((DIM,), device="cuda", generator=gen)).cpu().numpy()
+    rng = np.random.default_rng(5)
+    far = lambda: rng.standard_normal(DIM).astype(np.float32)
+    qs = np.stack([far(), near(), far(), far(), near(), near(), far(), near(),      # a group of 8
+                   near(), far(), far(), near(),                                    # a group of 4
+                   far(), near()])                                                  # a group of 2
+    t.set_option("prefilter", 0)
+    want = [t.knn(q, k) for q in qs]
+    t.set_option("prefilter", 2)
+    t.set_option("prefilter_adaptive", 0)            # every query tries stage 1 (the adaptive rule would switch it off here)
+    fell = []
+    for q in qs:                                     # which queries fall back, one at a time
+        _same(t.knn(q, k), want[len(fell)])
+        fell.append(bool(t.prefilter_stats()[1]))
+    assert fell == [False, True, False, False, True, True, False, True, True, False, False, True, False, True], fell
+    got = t.knn(qs, k)                               # 14 = 8 + 4 + 2: three groups
+    for u in range(len(qs)):
+        assert np.array_equal(got[0][u], want[u][0]), u
+        assert np.array_equal(got[1][u].view(np.uint32), want[u][1].view(np.uint32)), u
     t.close()

@@ -1,0 +1,74 @@
+// Dev harness: gemm_bf16_pp_kernel alone on the tower's four shapes at the HALF-chunk and the full-chunk row count, as a
+// back-to-back rate (20 launches between two events) and as ISOLATED launches (one launch between two events, the stream
+// drained around it, a 512 MB copy in between so that the operands come from HBM as they do in the tower).
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off tools/probe/gemm_pp_sweep.hip -o tools/probe/gemm_pp_sweep
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include "../../include/mi355clip.h"
+#include "../../image_search_amd/csrc/vit_kernels.h"
+using namespace mi;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+__global__ void fill_bf16(bf16_t* p, size_t n, uint64_t seed, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t z = (i + seed) * 0x9E3779B97F4A7C15ull; z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+        p[i] = f2bf(((int)(z & 0xffff) - 32768) / 32768.0f * scale);
+    }
+}
+__global__ void copy16(const v4u* a, v4u* b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+int main(int argc, char** argv) {
+    const int split = argc > 1 ? atoi(argv[1]) : 1;
+    struct Shape { int N, K; const char* name; } shapes[] = {{3072, 1024, "qkv"}, {1024, 1024, "out"}, {4096, 1024, "fc1"}, {1024, 4096, "fc2"}};
+    const size_t Mmax = 65792;
+    bf16_t *X, *W, *O; float* bias; char *junk, *junk2;
+    CK(hipMalloc(&X, Mmax * 4096 * 2)); CK(hipMalloc(&W, (size_t)4096 * 4096 * 2)); CK(hipMalloc(&O, Mmax * 4096 * 2));
+    CK(hipMalloc(&bias, 4096 * 4)); CK(hipMemset(bias, 0, 4096 * 4));
+    const size_t big = (size_t)512 << 20;
+    CK(hipMalloc(&junk, big)); CK(hipMalloc(&junk2, big)); CK(hipMemset(junk, 1, big));
+    hipLaunchKernelGGL(fill_bf16, 2048, 256, 0, 0, X, Mmax * 4096, 1, 1.0f);
+    hipLaunchKernelGGL(fill_bf16, 2048, 256, 0, 0, W, (size_t)4096 * 4096, 7, 0.05f);
+    auto k1 = gemm_bf16_pp_kernel<EPI_BIAS, bf16_t>;
+    auto k2 = gemm_bf16_pp_kernel<EPI_BIAS_QGELU, bf16_t>;
+    CK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 151552));
+    CK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 151552));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (size_t Mrows : {(size_t)32896, (size_t)65792}) {
+        const size_t Mp = (Mrows + 255) / 256 * 256;
+        for (auto& s : shapes) {
+            const double flop = 2.0 * Mrows * s.N * s.K;
+            const int n_tiles = (int)((Mp / 256) * (s.N / 256)), grid = std::min(n_tiles * 4, 256);
+            const int left = n_tiles % grid;
+            const int n_full = (split && left > 0 && left * 4 <= grid) ? n_tiles - left : n_tiles;
+            auto launch = [&] {
+                if (s.N == 4096) hipLaunchKernelGGL(k2, dim3(grid), dim3(512), 151552, 0, X, W, bias, (void*)O, (int)Mp, s.N, s.K, s.N, n_tiles, n_full, 0);
+                else hipLaunchKernelGGL(k1, dim3(grid), dim3(512), 151552, 0, X, W, bias, (void*)O, (int)Mp, s.N, s.K, s.N, n_tiles, n_full, 0);
+            };
+            for (int i = 0; i < 3; ++i) launch();
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 20; ++i) launch();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            const double rate_us = ms / 20 * 1e3;
+            double iso_warm = 0, iso_cold = 0;
+            for (int c = 0; c < 2; ++c) {
+                double acc = 0;
+                for (int i = 0; i < 8; ++i) {
+                    if (c == 1) hipLaunchKernelGGL(copy16, 2048, 256, 0, 0, (const v4u*)junk, (v4u*)junk2, big / 16);
+                    CK(hipDeviceSynchronize());
+                    CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (i >= 2) acc += ms * 1e3 / 6;
+                }
+                (c ? iso_cold : iso_warm) = acc;
+            }
+            printf("M=%zu %s N=%d K=%d tiles=%d (%.3f rounds, tail tasks %d): back-to-back %.1f us = %.0f TF | isolated warm %.1f us = %.0f TF | isolated behind 512 MB of other traffic %.1f us = %.0f TF\n",
+                   Mrows, s.name, s.N, s.K, n_tiles, n_tiles / 256.0, (n_tiles - n_full) * 4, rate_us, flop / rate_us / 1e6, iso_warm, flop / iso_warm / 1e6,
+                   iso_cold, flop / iso_cold / 1e6);
+        }
+    }
+    return 0;
+}
