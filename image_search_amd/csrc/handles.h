@@ -122,6 +122,10 @@ struct mi_knn {
     bool g8_ready = false;
     size_t scale8_cap = 0, cfac8_cap = 0, rho8_cap = 0, g8_cap = 0;
     float* d_xx = nullptr;
+    bool batch_stage1_mfma = true;  // the shared stage 1 of a group of queries on the matrix pipe (option "batch_stage1")
+    int8_t* d_digits = nullptr;     // [8][3][dim]: the queries of a group as three signed 7-bit digits
+    float* d_qs = nullptr;          // [8][4]: {digit scale S, |q|, rho, -}
+    size_t digits_cap = 0, qs_cap = 0;
     uint64_t mirror_rows = 0;
     size_t mirror_cap = 0, xx_cap = 0;
     uint64_t g8_rows = 0;              // rows the table held when the channel scales were taken (refreshed at 4x)

@@ -161,6 +161,24 @@ bool prefilter_applies(const mi_knn* t, uint32_t k) {
 template <int NCH>
 void launch_coarse8_batched(mi_knn* t, const uint8_t* m8, const float* d_q, float e0, uint32_t nq, uint32_t blocks, hipStream_t s) {
     if constexpr (NCH == 12) {  // built for dim 768, the width of the reference's table (server/src/clip.rs:140-143)
+        if (t->batch_stage1_mfma) {
+            // the group's stage 1 on the matrix pipe: exact int8 dot products against the query cut into three 7-bit digits
+            hipLaunchKernelGGL(knn_query_digits_kernel, dim3(nq), dim3(256), 0, s, d_q, t->d_g8, (int)t->dim, t->d_digits, t->d_qs, t->d_rho8);
+            constexpr int LDS = c8m_lds_bytes(NCH * 64);
+            const uint64_t n_tiles = (t->rows + 15) / 16;
+            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)t->n_cu, (n_tiles + 3) / 4));   // 153 KB of LDS: one workgroup per CU
+            if (nq <= 5) {
+                allow_lds(knn_scan_coarse8_mfma_kernel<NCH, 1>, LDS);
+                hipLaunchKernelGGL((knn_scan_coarse8_mfma_kernel<NCH, 1>), dim3(grid), dim3(256), LDS, s, m8, t->d_xx, t->d_scale8, t->d_cfac8, t->rows,
+                                   t->d_digits, t->d_qs, (int)nq, e0, t->d_keys32, (uint64_t)t->cap);
+            } else {
+                allow_lds(knn_scan_coarse8_mfma_kernel<NCH, 2>, LDS);
+                hipLaunchKernelGGL((knn_scan_coarse8_mfma_kernel<NCH, 2>), dim3(grid), dim3(256), LDS, s, m8, t->d_xx, t->d_scale8, t->d_cfac8, t->rows,
+                                   t->d_digits, t->d_qs, (int)nq, e0, t->d_keys32, (uint64_t)t->cap);
+            }
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         if (nq == 8)
             hipLaunchKernelGGL((knn_scan_coarse8_batched_kernel<NCH, 8>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8, t->d_cfac8,
                                t->d_g8, t->rows, d_q, e0, t->d_keys32, (uint64_t)t->cap, t->d_rho8);
@@ -209,6 +227,8 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s,
         ensure_keep(t, (void**)&t->d_scale8, &t->scale8_cap, (size_t)t->cap, sizeof(float), (size_t)t->mirror_rows);
         ensure_keep(t, (void**)&t->d_cfac8, &t->cfac8_cap, (size_t)t->cap, sizeof(float), (size_t)t->mirror_rows);
         ensure(t, (void**)&t->d_rho8, &t->rho8_cap, (size_t)8, sizeof(float));
+        ensure(t, (void**)&t->d_digits, &t->digits_cap, (size_t)8 * 3 * t->dim + 64, sizeof(int8_t));   // a group's queries as int8 digits
+        ensure(t, (void**)&t->d_qs, &t->qs_cap, (size_t)8 * 4, sizeof(float));
         ensure(t, (void**)&t->d_g8, &t->g8_cap, (size_t)2 * t->dim, sizeof(float));
         if (!t->g8_ready) {  // the channel scales: RMS per dimension over a sample spread over the table (any positive values are correct)
             const uint64_t sample = std::min<uint64_t>(t->rows, 1u << 16), stride = t->rows / sample;
@@ -563,6 +583,7 @@ int mi_knn_create(uint32_t dim, int device, mi_knn** out) {
         HIP_CHECK(hipMalloc((void**)&t->d_q, (size_t)16 * dim * sizeof(float)));
         if (const char* e = std::getenv("MI_KNN_SELECT")) t->select_path = std::atoi(e) != 0;  // A/B hook, read at creation
         if (const char* e = std::getenv("MI_KNN_RING")) t->coarse_ring = std::atoi(e) == 8 ? 8 : 4;
+        if (const char* e = std::getenv("MI_KNN_BATCH_STAGE1")) t->batch_stage1_mfma = std::atoi(e) != 0;  // A/B hook, read at creation
         *out = t;
     });
 }
@@ -577,7 +598,7 @@ void mi_knn_free(mi_knn* t) {
     for (void* p : {(void*)t->table, (void*)t->d_q, (void*)t->d_cand, (void*)t->d_tmp, (void*)t->d_keys,
                     (void*)t->d_idx, (void*)t->d_dist, (void*)t->d_keys32, (void*)t->d_sel, (void*)t->d_mirror,
                     (void*)t->d_xx, (void*)t->d_pref_rows, (void*)t->d_pref_keys, (void*)t->d_pref_flag, (void*)t->d_scale8,
-                    (void*)t->d_cfac8, (void*)t->d_rho8, (void*)t->d_g8})
+                    (void*)t->d_cfac8, (void*)t->d_rho8, (void*)t->d_g8, (void*)t->d_digits, (void*)t->d_qs})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : t->pref_ev)
         if (e) (void)hipEventDestroy(e);
@@ -605,6 +626,10 @@ int mi_knn_set_option(mi_knn* t, const char* key, int value) {
             }
             if (value != t->prefilter) pref_reset(t);
             t->prefilter = value;
+        } else if (k == "batch_stage1") {
+            // 1 (default): the shared stage 1 of a group of queries on the matrix pipe (int8 MFMA, knn_scan_coarse8_mfma_kernel);
+            // 0: the vector-ALU form (knn_scan_coarse8_batched_kernel).  Same answers either way.
+            t->batch_stage1_mfma = value != 0;
         } else if (k == "prefilter_adaptive") {
             // 1 (default): a corpus that makes the two-stage search FALL BACK twice in a row is served by the single pass alone
             // for the next 64 single-query searches, then probed again with two queries (only fallbacks count: the candidate
@@ -612,7 +637,7 @@ int mi_knn_set_option(mi_knn* t, const char* key, int value) {
             pref_reset(t);
             t->pref_adaptive = value != 0;
         } else {
-            fail(MI_ERR_INVALID, "unknown option '%s' (known: prefilter, prefilter_adaptive)", key);
+            fail(MI_ERR_INVALID, "unknown option '%s' (known: prefilter, prefilter_adaptive, batch_stage1)", key);
         }
     });
 }

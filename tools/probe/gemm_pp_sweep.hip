@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 151552));
     CK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 151552));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (size_t Mrows : {(size_t)32896, (size_t)65792}) {
+    for (size_t Mrows : {(size_t)32768, (size_t)32896, (size_t)65536, (size_t)65792}) {   // whole rounds of tiles (no tail) beside the tower's row counts
         const size_t Mp = (Mrows + 255) / 256 * 256;
         for (auto& s : shapes) {
             const double flop = 2.0 * Mrows * s.N * s.K;
