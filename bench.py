@@ -583,9 +583,22 @@ def main():
             table.set_option("prefilter", 2)
             ms8t, i8t, b8t = time_batched(table, args.k, 8, 10)
             extra["knn_10m_batched8"].update({"two_stage_ms_per_call": round(ms8t, 4), "two_stage_queries_per_sec": round(8e3 / ms8t, 1),
-                                              "two_stage_equal": bool(np.array_equal(i8, i8t) and np.array_equal(b8, b8t))})
+                                              "two_stage_equal": bool(np.array_equal(i8, i8t) and np.array_equal(b8, b8t)),
+                                              "stage1": "int8 MFMA over the byte mirror, one launch per kernel for the group"})
             two_stage_equal = bool(two_stage_equal and extra["knn_10m_batched8"]["two_stage_equal"])
+            # 16 queries per call: one group on the matrix pipe; the reference answers from two passes of 8 over the fp32 rows
+            ms16t, i16t, b16t = time_batched(table, args.k, 16, 10)
             table.set_option("prefilter", 0)
+            _, i16a, b16a = time_batched(table, args.k, 8, 1)
+            d_q2 = d_q[8:16].contiguous()
+            d_i2 = torch.empty((8, args.k), dtype=torch.int64, device="cuda"); d_d2 = torch.empty((8, args.k), dtype=torch.float32, device="cuda")
+            table.knn_device(d_q2.data_ptr(), 8, args.k, d_i2.data_ptr(), d_d2.data_ptr(), stream.cuda_stream, batched=True)
+            stream.synchronize()
+            ref_i = np.concatenate([i16a, d_i2.cpu().numpy()]); ref_b = np.concatenate([b16a, d_d2.cpu().numpy().view(np.uint32)])
+            extra["knn_10m_batched16"] = {"config": f"16 queries per call, cosine top-{args.k} over {rows_total} x 768 f32, two-stage exact search, one group",
+                                          "two_stage_ms_per_call": round(ms16t, 4), "two_stage_queries_per_sec": round(16e3 / ms16t, 1),
+                                          "two_stage_equal": bool(np.array_equal(i16t, ref_i) and np.array_equal(b16t, ref_b))}
+            two_stage_equal = bool(two_stage_equal and extra["knn_10m_batched16"]["two_stage_equal"])
         m32 = Model.from_file(wpath, local, PRECISION_F32)
         d_img = torch.from_numpy(np.ascontiguousarray(pins[0].array[:32])).cuda()
         d_emb = torch.empty((32, cfg.proj), dtype=torch.float32, device="cuda")

@@ -167,15 +167,17 @@ void launch_coarse8_batched(mi_knn* t, const uint8_t* m8, const float* d_q, floa
             constexpr int LDS = c8m_lds_bytes(NCH * 64);
             const uint64_t n_tiles = (t->rows + 15) / 16;
             const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)t->n_cu, (n_tiles + 3) / 4));   // 153 KB of LDS: one workgroup per CU
-            if (nq <= 5) {
-                allow_lds(knn_scan_coarse8_mfma_kernel<NCH, 1>, LDS);
-                hipLaunchKernelGGL((knn_scan_coarse8_mfma_kernel<NCH, 1>), dim3(grid), dim3(256), LDS, s, m8, t->d_xx, t->d_scale8, t->d_cfac8, t->rows,
-                                   t->d_digits, t->d_qs, (int)nq, e0, t->d_keys32, (uint64_t)t->cap);
-            } else {
-                allow_lds(knn_scan_coarse8_mfma_kernel<NCH, 2>, LDS);
-                hipLaunchKernelGGL((knn_scan_coarse8_mfma_kernel<NCH, 2>), dim3(grid), dim3(256), LDS, s, m8, t->d_xx, t->d_scale8, t->d_cfac8, t->rows,
-                                   t->d_digits, t->d_qs, (int)nq, e0, t->d_keys32, (uint64_t)t->cap);
-            }
+#define MI_C8M(NBLK, QPB)                                                                                                         \
+    {                                                                                                                             \
+        allow_lds(knn_scan_coarse8_mfma_kernel<NCH, NBLK, QPB>, LDS);                                                             \
+        hipLaunchKernelGGL((knn_scan_coarse8_mfma_kernel<NCH, NBLK, QPB>), dim3(grid), dim3(256), LDS, s, m8, t->d_xx, t->d_scale8, \
+                           t->d_cfac8, t->rows, t->d_digits, t->d_qs, (int)nq, e0, t->d_keys32, (uint64_t)t->cap);                \
+    }
+            if (nq <= 5) MI_C8M(1, 5)
+            else if (nq <= 10) MI_C8M(2, 5)
+            else if (nq <= 15) MI_C8M(3, 5)
+            else MI_C8M(4, 4)
+#undef MI_C8M
             HIP_CHECK(hipGetLastError());
             return;
         }
@@ -194,6 +196,12 @@ void launch_coarse8_batched(mi_knn* t, const uint8_t* m8, const float* d_q, floa
 }
 // the strides of a group of gy queries on the shard's workspaces (every per-query buffer holds gy copies back to back)
 constexpr uint32_t SEL_WORDS = 6 * SEL_BINS + 64;
+constexpr uint32_t KNN_GROUP_MAX = 16;   // queries that share one pass over the byte mirror (matrix-pipe stage 1; the vector-ALU form: 8)
+// how many of `left` >= 2 queries the next group takes: any count up to 16 on the matrix pipe, 8 / 4 / 2 on the vector ALU
+uint32_t group_size(const mi_knn* t, uint32_t left) {
+    if (t->batch_stage1_mfma) return std::min(left, KNN_GROUP_MAX);
+    return left >= 8 ? 8 : left >= 4 ? 4 : 2;
+}
 QGroup group_of(const mi_knn* t, uint32_t gy) {
     QGroup g;
     if (gy <= 1) return g;
@@ -226,9 +234,9 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s,
     if (bytes) {
         ensure_keep(t, (void**)&t->d_scale8, &t->scale8_cap, (size_t)t->cap, sizeof(float), (size_t)t->mirror_rows);
         ensure_keep(t, (void**)&t->d_cfac8, &t->cfac8_cap, (size_t)t->cap, sizeof(float), (size_t)t->mirror_rows);
-        ensure(t, (void**)&t->d_rho8, &t->rho8_cap, (size_t)8, sizeof(float));
-        ensure(t, (void**)&t->d_digits, &t->digits_cap, (size_t)8 * 3 * t->dim + 64, sizeof(int8_t));   // a group's queries as int8 digits
-        ensure(t, (void**)&t->d_qs, &t->qs_cap, (size_t)8 * 4, sizeof(float));
+        ensure(t, (void**)&t->d_rho8, &t->rho8_cap, (size_t)KNN_GROUP_MAX, sizeof(float));
+        ensure(t, (void**)&t->d_digits, &t->digits_cap, (size_t)KNN_GROUP_MAX * 3 * t->dim + 64, sizeof(int8_t));   // a group's queries as int8 digits
+        ensure(t, (void**)&t->d_qs, &t->qs_cap, (size_t)KNN_GROUP_MAX * 4, sizeof(float));
         ensure(t, (void**)&t->d_g8, &t->g8_cap, (size_t)2 * t->dim, sizeof(float));
         if (!t->g8_ready) {  // the channel scales: RMS per dimension over a sample spread over the table (any positive values are correct)
             const uint64_t sample = std::min<uint64_t>(t->rows, 1u << 16), stride = t->rows / sample;
@@ -895,8 +903,8 @@ int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint3
         uint32_t u = 0;
         while (u < nq) {
             const uint32_t left = nq - u;
-            if (left >= 2 && batched_two_stage_applies(t, k)) {  // one pass over the byte mirror serves 8, 4 or 2 queries
-                const uint32_t b2 = left >= 8 ? 8 : left >= 4 ? 4 : 2;
+            if (left >= 2 && batched_two_stage_applies(t, k)) {  // one pass over the byte mirror serves a group of up to 16 queries
+                const uint32_t b2 = group_size(t, left);
                 search_batched_two_stage(t, d_q + (size_t)u * t->dim, b2, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
                 u += b2;
                 continue;
@@ -945,7 +953,7 @@ int mi_knn_search(mi_knn* t, const float* q, uint32_t nq, uint32_t k, uint64_t* 
             while (u < ng) {
                 const uint32_t left = ng - u;
                 if (left >= 2 && batched_two_stage_applies(t, k)) {
-                    const uint32_t b2 = left >= 8 ? 8 : left >= 4 ? 4 : 2;
+                    const uint32_t b2 = group_size(t, left);
                     search_batched_two_stage(t, t->d_q + (size_t)u * t->dim, b2, k, t->d_idx + (size_t)u * k, t->d_dist + (size_t)u * k, t->stream);
                     u += b2;
                     continue;

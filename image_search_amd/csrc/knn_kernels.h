@@ -1014,14 +1014,15 @@ __global__ __launch_bounds__(256) void knn_query_digits_kernel(const float* __re
     }
 }
 
-// NBLK column blocks of 16 digit columns: 1 (up to 5 queries) or 2 (up to 10); all_keys: [nq][key_stride]
-template <int NCH, int NBLK>
+// NBLK column blocks of 16 digit columns with QPB queries (3 QPB <= 16 columns) each: <1,5> up to 5 queries, <2,5> up to 10,
+// <3,5> up to 15, <4,4> 16; all_keys: [nq][key_stride]
+template <int NCH, int NBLK, int QPB>
 __global__ __launch_bounds__(256, 1) void knn_scan_coarse8_mfma_kernel(const uint8_t* __restrict__ mirror, const float* __restrict__ xx,
                                                                      const float* __restrict__ scale, const float* __restrict__ cfac,
                                                                      uint64_t n_rows, const int8_t* __restrict__ digits,
                                                                      const float* __restrict__ qs, int nq, float e0,
                                                                      uint32_t* __restrict__ all_keys, uint64_t key_stride) {
-    static_assert(NCH % 4 == 0, "rows of whole 256-byte chunks");
+    static_assert(NCH % 4 == 0 && 3 * QPB <= 16, "rows of whole 256-byte chunks; a block's digit columns fit 16");
     constexpr int DIM = NCH * 64, STEPS = DIM / 64, NDMA = DIM / 64, TILE = c8m_tile_bytes(DIM), ROWS = 16 * DIM;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -1031,14 +1032,14 @@ __global__ __launch_bounds__(256, 1) void knn_scan_coarse8_mfma_kernel(const uin
     const uint32_t wave = blockIdx.x * 4 + wib, n_waves = gridDim.x * 4;
     const uint64_t n_tiles = (n_rows + 15) >> 4;
 
-    // the digit fragments of this lane's column: column n of block b is digit d = n % 3 of query 5 b + n / 3
+    // the digit fragments of this lane's column: column n of block b is digit d = n % 3 of query QPB b + n / 3
     v4i32 bf[NBLK][STEPS];
     float S[NBLK], sqn[NBLK], rho[NBLK];
     int qcol[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
-        const int qi = 5 * b + n / 3, d = n % 3;
-        const bool live = n < 15 && qi < nq;
+        const int qi = QPB * b + n / 3, d = n % 3;
+        const bool live = n < 3 * QPB && qi < nq;
         qcol[b] = live && d == 0 ? qi : -1;
         S[b] = live ? qs[4 * qi + 0] : 0.0f; sqn[b] = live ? qs[4 * qi + 1] : 1.0f; rho[b] = live ? qs[4 * qi + 2] : 0.0f;
 #pragma unroll

@@ -178,6 +178,9 @@ int mi_knn_set_base(mi_knn* t, uint64_t base);
  * independent; 2: per row and query) cannot exclude are re-evaluated from the fp32 rows with the single-pass arithmetic:
  * same ids, same distance bits, a half (1) or a quarter (2) of the bytes per query.  Corpora that put more than 2^22
  * rows inside the bound fall back to the single pass on the device.  0 (default) frees the mirror.
+ * "batch_stage1" = 1 (default) / 0: how a GROUP of queries (mi_knn_search with nq >= 2, mi_knn_search_batched_device) runs its
+ * shared stage 1 over the byte mirror: 1 on the matrix pipe (any group size up to 16; HBM-bound), 0 on the vector ALU
+ * (groups of 8 / 4 / 2; the round-3 form, kept for A/B).  Same answers either way.
  * "prefilter_adaptive" = 1 (default) / 0: the two-stage search watches itself — candidate counts and fallbacks are read
  * back asynchronously; after two consecutive fallbacks (more than 2^22 candidates) the next 64 single-query searches run
  * the single pass alone (what such a corpus would pay anyway, without stage 1 on top), then stage 1 is probed again with
@@ -230,9 +233,11 @@ int mi_knn_search(mi_knn* t, const float* q, uint32_t nq, uint32_t k, uint64_t* 
  * all-gather when the table is sharded. */
 int mi_knn_search_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx,
                          float* d_dist, void* stream);
-/* Throughput variant: ONE pass over the table serves all nq queries (nq <= 16; passes of 8 / 4 / 2 queries — over the byte
- * mirror when "prefilter" = 2 is on and dim is 768: one stage-1 pass for the group, a stage 2 per query; over the fp32
- * rows otherwise, k <= 64); results identical to nq calls of mi_knn_search_device with nq = 1. */
+/* Throughput variant: ONE pass over the table serves all nq queries (nq <= 16).  With "prefilter" = 2 and dim 768 the whole
+ * group of up to 16 queries shares one pass over the byte mirror on the matrix pipe (the queries cut into three signed 7-bit
+ * digits, exact int8 MFMA dot products; option "batch_stage1" = 0: the vector-ALU form, groups of 8 / 4 / 2) and ONE launch
+ * of every later kernel of the two-stage search; otherwise passes of 8 / 4 / 2 queries over the fp32 rows (k <= 64).
+ * Results identical to nq calls of mi_knn_search_device with nq = 1: same ids, same distance bits. */
 int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx,
                                  float* d_dist, void* stream);
 

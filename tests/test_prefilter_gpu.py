@@ -419,7 +419,9 @@ def test_a_growing_table_keeps_its_mirror_and_refreshes_the_channel_scales_at_4x
 @pytest.mark.parametrize("k", [1, 10, 64, 1000])
 def test_batched_queries_share_one_pass_over_the_byte_mirror(built, k):
     """mi_knn_search with nq > 1 and mi_knn_search_batched_device used to bypass the prefilter.  With the
-    byte mirror 8, 4 or 2 queries now share ONE stage-1 pass (knn_scan_coarse8_batched_kernel: a query per 16-lane group)
+    byte mirror a group of queries shares ONE stage-1 pass — round 3: 8, 4 or 2 queries on the vector ALU
+    (knn_scan_coarse8_batched_kernel: a query per 16-lane group); round 4: any group size up to 16 on the matrix pipe
+    (knn_scan_coarse8_mfma_kernel: the queries as int8 digits, exact integer dot products) —
     and, since round 4, ONE launch of every later kernel — selects, collect, stage 2, select over the candidates, sort,
     the gated single pass, finalize — with the query as grid.y on per-query workspaces (QGroup): ids and distance bits of nq
     single searches."""
@@ -427,22 +429,27 @@ def test_batched_queries_share_one_pass_over_the_byte_mirror(built, k):
     t = EmbeddingTable(DIM, 0)
     t.insert_synthetic(31, 0, N + 1234)                         # a ragged last tile
     rng = np.random.default_rng(100 + k)
-    qs = rng.standard_normal((13, DIM)).astype(np.float32)
+    qs = rng.standard_normal((16, DIM)).astype(np.float32)
     qs[3] = t.rows(777, 1)[0]                                   # a stored row as a query
     qs[9] = 0.0                                                 # a zero query: every distance NaN
     want = t.knn(qs, k)                                         # prefilter off: the single pass (batched fp32 kernel for k <= 64)
     t.set_option("prefilter", 2)
     singles = [t.knn(q, k) for q in qs]                         # two-stage, one query at a time
-    for u in range(13):
+    for u in range(16):
         assert np.array_equal(singles[u][0], want[0][u]) and np.array_equal(singles[u][1].view(np.uint32), want[1][u].view(np.uint32))
-    got = t.knn(qs, k)                                          # 13 = 8 + 4 + 1: two shared passes and a single search
+    got = t.knn(qs, k)                                          # 16 queries: ONE group on the matrix pipe (8 + 8 on the vector ALU)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
     cand, fell_back = t.prefilter_stats()
     assert not fell_back and cand >= min(k, 1)
     d_q = torch.from_numpy(qs).cuda()
-    d_i = torch.empty((13, k), dtype=torch.int64, device="cuda")
-    d_d = torch.empty((13, k), dtype=torch.float32, device="cuda")
-    for nq in (2, 3, 4, 6, 7, 8, 12, 13):                       # shared passes of 8, 4 and 2 queries, single searches for the odd one
+    d_i = torch.empty((16, k), dtype=torch.int64, device="cuda")
+    d_d = torch.empty((16, k), dtype=torch.float32, device="cuda")
+    for stage1 in (1, 0):                                       # the group's stage 1 on the matrix pipe (default), then on the vector ALU
+        t.set_option("batch_stage1", stage1)
+        got = t.knn(qs, k)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32)), stage1
+    t.set_option("batch_stage1", 1)
+    for nq in (2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 15, 16):    # every group size: 1 to 4 column blocks of digit columns
         d_i.zero_(); d_d.zero_()
         t.knn_device(d_q.data_ptr(), nq, k, d_i.data_ptr(), d_d.data_ptr(), torch.cuda.current_stream().cuda_stream, batched=True)
         torch.cuda.synchronize()
