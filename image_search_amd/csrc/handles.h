@@ -226,6 +226,7 @@ void clip_forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStr
 hipStream_t knn_own_stream(mi_knn* t);
 void knn_grow(mi_knn* t, uint64_t want_rows);       // may reallocate: waits for the handle's pending work
 void knn_search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s);
+void knn_search_many(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s);  // nq queries in groups that share their passes; results [nq][k]
 void knn_truncate(mi_knn* t, uint64_t rows);        // forget the rows behind `rows` (a failed multi-shard append / load rolls back)
 // list l of query u: ids at d_idx_in + l * idx_stride + u * k, distances at d_dist_in + l * dist_stride + u * k (elements)
 void knn_merge_lists_device(const uint64_t* d_idx_in, const float* d_dist_in, uint32_t lists, uint32_t nq, uint32_t k,

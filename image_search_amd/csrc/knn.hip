@@ -549,10 +549,31 @@ void check_search_args(const mi_knn* t, const void* q, uint32_t nq, uint32_t k, 
     if (k == 0) fail(MI_ERR_INVALID, "k must be >= 1");
 }
 
+// nq queries on the device (contiguous at d_q), in groups that share their passes: up to 16 per group through the two-stage
+// search over the byte mirror, else 8 / 4 / 2 over the fp32 rows (k <= 64), else one by one; results [nq][k]
+void search_many(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
+    uint32_t u = 0;
+    while (u < nq) {
+        const uint32_t left = nq - u;
+        if (left >= 2 && t->rows && batched_two_stage_applies(t, k)) {  // one pass over the byte mirror serves a group of up to 16 queries
+            const uint32_t b2 = group_size(t, left);
+            search_batched_two_stage(t, d_q + (size_t)u * t->dim, b2, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
+            u += b2;
+            continue;
+        }
+        const uint32_t b = (k <= 64 && t->rows && t->dim == 768) ? (left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1) : 1;
+        if (b == 1) search_one(t, d_q + (size_t)u * t->dim, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
+        else search_batched(t, d_q + (size_t)u * t->dim, b, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
+        u += b;
+    }
+}
 }  // namespace
 
 namespace mi {
 hipStream_t knn_own_stream(mi_knn* t) { return own_stream(t); }
+void knn_search_many(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
+    search_many(t, d_q, nq, k, d_idx, d_dist, s);
+}
 void knn_grow(mi_knn* t, uint64_t want_rows) { grow(t, want_rows); }
 void knn_search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
     search_one(t, d_q, k, d_idx, d_dist, s);
@@ -900,20 +921,7 @@ int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint3
         hipStream_t s = stream ? (hipStream_t)stream : own_stream(t);
         t->writes.begin(s);
         t->reads.begin(s);
-        uint32_t u = 0;
-        while (u < nq) {
-            const uint32_t left = nq - u;
-            if (left >= 2 && batched_two_stage_applies(t, k)) {  // one pass over the byte mirror serves a group of up to 16 queries
-                const uint32_t b2 = group_size(t, left);
-                search_batched_two_stage(t, d_q + (size_t)u * t->dim, b2, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
-                u += b2;
-                continue;
-            }
-            const uint32_t b = (k <= 64 && t->rows && t->dim == 768) ? (left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1) : 1;
-            if (b == 1) search_one(t, d_q + (size_t)u * t->dim, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
-            else search_batched(t, d_q + (size_t)u * t->dim, b, k, d_idx + (size_t)u * k, d_dist + (size_t)u * k, s);
-            u += b;
-        }
+        search_many(t, d_q, nq, k, d_idx, d_dist, s);
         t->reads.end(s);
     });
 }

@@ -286,9 +286,8 @@ void sharded_search_enqueue(mi_knn_sharded* t, const float* q, uint32_t nq, uint
         HIP_CHECK(hipMemcpyAsync(sl.d_q[s].p, sl.h_q.p, (size_t)nq * t->dim * 4, hipMemcpyHostToDevice, st));
         sh->writes.begin(st);
         sh->reads.begin(st);
-        for (uint32_t u = 0; u < nq; ++u)
-            knn_search_one(sh, (const float*)sl.d_q[s].p + (size_t)u * t->dim, k, rec_idx(sl.d_rec[s].p) + (size_t)u * k,
-                           rec_dist(sl.d_rec[s].p) + (size_t)u * k, st);
+        // several queries per call share their passes over the shard (groups of up to 16 through the two-stage search)
+        knn_search_many(sh, (const float*)sl.d_q[s].p, nq, k, rec_idx(sl.d_rec[s].p), rec_dist(sl.d_rec[s].p), st);
         sh->reads.end(st);
     }
     mi_knn* first = t->shard[0];
