@@ -47,6 +47,7 @@ struct mi_clip {
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     static constexpr int N_EV_SCHED = 256;   // events that tie the R stream and the LayerNorm streams of a scheduled forward (a ring, created on first use)
     hipEvent_t ev_sched[N_EV_SCHED] = {};
+    bool x24 = true;          // bf16 image tower: the residual stream as 24-bit floats in two planes (3 bytes per element instead of 4; option "x24", MI_CLIP_X24)
     int part0_short = 0;      // two-part forward: the first part takes n/2 - part0_short images (option "part0_short")
     int sched = 0;            // how a two-part forward is ordered on the chip (forward() in vit.hip; option "sched" / MI_CLIP_SCHED)
     int parts = 2;  // MI_CLIP_PARTS: sub-chunks run as independent streams

@@ -319,16 +319,17 @@ void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out
     }
 
 // y pitch: D, or 2D with the lo halves behind the hi halves (split_ln)
+// x_lo: byte offset of the lo plane when x is the 24-bit residual stream (0: plain fp32 rows)
 void layer_norm(mi_clip* m, float* x, const bf16_t* d1, const bf16_t* d2, bool write_back, void* y, const float* w,
-                const float* b, size_t rows, hipStream_t s) {
+                const float* b, size_t rows, hipStream_t s, size_t x_lo = 0) {
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     const int split = m->split_ln ? 1 : 0, y_ld = m->D * (1 + split);
     if (m->precision == MI_PRECISION_F32) {
         MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<float, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (float*)y, w, b, (int)rows, m->eps, y_ld, 0));
     } else if (write_back) {
-        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, y_ld, split, m->ln_nt));
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, y_ld, split, m->ln_nt, x_lo));
     } else {
-        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, false>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, y_ld, split));
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, false>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, y_ld, split, 0, x_lo));
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -403,7 +404,9 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     //      LayerNorm always runs beside the other part's R block, and two GEMMs never share the chip.
     //   2: every part on its own stream as in 0, R blocks chained across the streams by events in the same order.
     const int sched = parts == 2 ? m->sched : 0;
-    struct Part { size_t n, M, P; const float* img; float* out; hipStream_t rs, ls; mi_clip::Act* a; const bf16_t *p1, *p2; } pt[4];
+    struct Part { size_t n, M, P; const float* img; float* out; hipStream_t rs, ls; mi_clip::Act* a; const bf16_t *p1, *p2; size_t xlo; } pt[4];
+    // the residual stream as 24-bit floats in two planes (option "x24"; bf16 tower, D a multiple of 256, no hi + lo LayerNorm outputs)
+    const bool x24 = deferred && m->x24 && !m->split_ln && D % 256 == 0;
     auto aux = [&](int i) {
         if (!m->aux[i]) HIP_CHECK(hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking));
         return m->aux[i];
@@ -416,7 +419,8 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
         hipStream_t rs = p == 0 ? s0 : nullptr, ls = nullptr;
         if (sched == 1) { rs = s0; ls = aux(0); }  // ONE LayerNorm stream: in the intended order they never overlap one another
         else { if (p > 0) rs = aux((int)p - 1); ls = rs; }
-        pt[p] = {np, np * S, np * (S - 1), d_img + first * px, d_out + first * m->E, rs, ls, &m->act[p], nullptr, nullptr};
+        pt[p] = {np, np * S, np * (S - 1), d_img + first * px, d_out + first * m->E, rs, ls, &m->act[p], nullptr, nullptr,
+                 x24 ? pad256(np * S) * (size_t)D * 2 : (size_t)0};   // the lo plane lies behind a hi plane of the part's padded rows
         first += np;
     }
     // Events are recorded the moment their producer is enqueued (an event recorded later would also cover whatever the
@@ -453,7 +457,7 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
         HIP_CHECK(hipGetLastError());
         gemm<EPI_STORE_F32>(m, q.a->col, m->wpatch, nullptr, q.a->patch, q.P, D, m->Kp, D, fs);
         const unsigned lb = (unsigned)((q.M + 3) / 4);
-        MI_LN_DISPATCH(D, hipLaunchKernelGGL((embed_ln_kernel<VEC, NT>), dim3(lb), dim3(256), 0, fs, q.a->patch, m->cls, m->pos, q.a->x, m->pre_w, m->pre_b, (int)q.M, S, m->eps));
+        MI_LN_DISPATCH(D, hipLaunchKernelGGL((embed_ln_kernel<VEC, NT>), dim3(lb), dim3(256), 0, fs, q.a->patch, m->cls, m->pos, q.a->x, m->pre_w, m->pre_b, (int)q.M, S, m->eps, q.xlo));
         HIP_CHECK(hipGetLastError());
     }
     // fp32 path: the residual add is the GEMM epilogue (x += acc + bias, fp32 read-modify-write).
@@ -485,7 +489,7 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
         for (int p = 0; p < parts; ++p) {
             Part& q = pt[p];
             ln_enter(p);
-            layer_norm(m, q.a->x, q.p1, q.p2, true, q.a->y, ly.ln1w, ly.ln1b, q.M, q.ls);
+            layer_norm(m, q.a->x, q.p1, q.p2, true, q.a->y, ly.ln1w, ly.ln1b, q.M, q.ls, q.xlo);
             ln_leave(p);
             if (sched == 0) {  // as launched since round 1: LN1, qkv, attention of every part, then the rest of every part
                 if (!last) gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, Kln, 3 * D, q.rs);
@@ -514,7 +518,8 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
                 const unsigned gb2 = gb;
                 if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb2), dim3(256), 0, s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_ctx, (int)q.n, (size_t)S, D);
                 else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb2), dim3(256), 0, s, (const float*)q.a->y, (float*)q.a->c_ctx, (int)q.n, (size_t)S, D);
-                hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb2), dim3(256), 0, s, (const float*)q.a->x, q.a->c_x, (int)q.n, (size_t)S, D);
+                if (q.xlo) hipLaunchKernelGGL(gather_rows_x24_kernel, dim3(gb2), dim3(256), 0, s, (const uint16_t*)q.a->x, (const uint8_t*)q.a->x + q.xlo, q.a->c_x, (int)q.n, (size_t)S, D);
+                else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb2), dim3(256), 0, s, (const float*)q.a->x, q.a->c_x, (int)q.n, (size_t)S, D);
                 HIP_CHECK(hipGetLastError());
                 if (deferred) {
                     gemm<EPI_BIAS>(m, q.a->c_ctx, ly.wo, ly.bo, q.a->c_d1, q.n, D, D, D, s);
@@ -541,7 +546,7 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
             if (sched != 0) r_leave(p);
             // ---- LN2 (L)
             ln_enter(p);
-            if (deferred) layer_norm(m, q.a->x, q.a->delta, nullptr, false, q.a->y, ly.ln2w, ly.ln2b, q.M, q.ls);
+            if (deferred) layer_norm(m, q.a->x, q.a->delta, nullptr, false, q.a->y, ly.ln2w, ly.ln2b, q.M, q.ls, q.xlo);
             else layer_norm(m, q.a->x, nullptr, nullptr, true, q.a->y, ly.ln2w, ly.ln2b, q.M, q.ls);
             ln_leave(p);
             if (sched == 0) {  // R2 right behind, on the part's own stream
@@ -566,7 +571,7 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
         Part& q = pt[p];
         ln_enter(p);
         // fp32 in both precisions: the embedding that goes to the table is not rounded to bf16 anywhere here
-        MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, q.ls, q.a->x, q.p1, q.p2, m->post_w, m->post_b, m->proj, q.out, (int)q.n, S, m->E, m->eps, (const int*)nullptr));
+        MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, q.ls, q.a->x, q.p1, q.p2, m->post_w, m->post_b, m->proj, q.out, (int)q.n, S, m->E, m->eps, (const int*)nullptr, q.xlo));
         HIP_CHECK(hipGetLastError());
     }
     if (parts > 1) {
@@ -816,6 +821,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         else if (k == "im2col_rows") m->im2col_rows = value != 0;
         else if (k == "text_fast") m->text_fast = value != 0;
         else if (k == "ln_nt") m->ln_nt = value & 3;
+        else if (k == "x24") m->x24 = value != 0;   // takes effect with the next forward (every forward rewrites the residual stream)
         else if (k == "grid_cus") {  // A/B hook: cap of the persistent kernels' grids (GEMM, attention); 0 = every CU
             if (value < 0 || value > 4096) fail(MI_ERR_INVALID, "grid_cus out of range");
             hipDeviceProp_t prop;
@@ -847,7 +853,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, im2col_rows, ln_nt, sched, text_fast, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, im2col_rows, ln_nt, sched, x24, part0_short, grid_cus, text_fast, max_batch, parts)", key);
     });
 }
 
@@ -875,6 +881,7 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         if (const char* e = std::getenv("MI_GEMM_SPLIT")) m->split_tail = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_CLIP_IM2COL")) m->im2col_rows = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_CLIP_LN_NT")) m->ln_nt = std::atoi(e) & 3;
+        if (const char* e = std::getenv("MI_CLIP_X24")) m->x24 = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_CLIP_SCHED")) m->sched = std::min(2, std::max(0, std::atoi(e)));
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));

@@ -187,6 +187,37 @@ struct LnRow {
 #pragma unroll
         for (int t = 0; t < NT; ++t) ld_vec<VEC>(&v[t * VEC], p + (t * 64 + lane) * VEC);
     }
+    // The residual stream as 24-BIT floats in two planes (option "x24", bf16 tower): hi = the top 16 bits of the fp32
+    // pattern (sign, exponent, 7 mantissa bits), lo = the next 8 mantissa bits — 16 significant bits, 3 bytes per element
+    // instead of 4.  The LayerNorms are pure HBM traffic and cost the forward their full stand-alone time:
+    // the fp32 residual is 12 of their 22 bytes per element and layer, this makes it 9.  Rounded to nearest when stored.
+    __device__ __forceinline__ void load_x24(const uint16_t* __restrict__ hi, const uint8_t* __restrict__ lo, int lane) {
+        static_assert(VEC == 4, "four elements per lane and chunk");
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const v2u h = *reinterpret_cast<const v2u*>(hi + (t * 64 + lane) * 4);
+            const uint32_t l = *reinterpret_cast<const uint32_t*>(lo + (t * 64 + lane) * 4);
+            v[t * 4 + 0] = __uint_as_float((h.x << 16) | ((l & 0xFFu) << 8));
+            v[t * 4 + 1] = __uint_as_float((h.x & 0xFFFF0000u) | (l & 0xFF00u));
+            v[t * 4 + 2] = __uint_as_float((h.y << 16) | ((l >> 8) & 0xFF00u));
+            v[t * 4 + 3] = __uint_as_float((h.y & 0xFFFF0000u) | ((l >> 16) & 0xFF00u));
+        }
+    }
+    __device__ __forceinline__ void store_x24(uint16_t* __restrict__ hi, uint8_t* __restrict__ lo, int lane) const {
+        static_assert(VEC == 4, "four elements per lane and chunk");
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            uint32_t r[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = __float_as_uint(v[t * 4 + c]) + 0x80u;   // round to 24 bits, nearest (ties up)
+            v2u h;
+            h.x = (r[0] >> 16) | (r[1] & 0xFFFF0000u);
+            h.y = (r[2] >> 16) | (r[3] & 0xFFFF0000u);
+            *reinterpret_cast<v2u*>(hi + (t * 64 + lane) * 4) = h;
+            *reinterpret_cast<uint32_t*>(lo + (t * 64 + lane) * 4) =
+                ((r[0] >> 8) & 0xFFu) | (r[1] & 0xFF00u) | ((r[2] << 8) & 0xFF0000u) | ((r[3] << 16) & 0xFF000000u);
+        }
+    }
     // last-use loads (LN1: the residual stream and the two deltas are not read again): non-temporal hint
     __device__ __forceinline__ void load_nt(const float* __restrict__ p, int lane) {
 #pragma unroll
@@ -287,12 +318,26 @@ template <typename T, int VEC, int NT, bool WRITE_BACK>
 __device__ __forceinline__ void ln_body(float* __restrict__ x, const bf16_t* __restrict__ d1,
                                                  const bf16_t* __restrict__ d2, T* __restrict__ y,
                                                  const float* __restrict__ w, const float* __restrict__ b, int rows,
-                                                 float eps, int y_ld, int split, int nt_x) {
+                                                 float eps, int y_ld, int split, int nt_x, size_t x_lo_off = 0) {
     constexpr int D = 64 * VEC * NT;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     LnRow<VEC, NT> r;
+    // x_lo_off != 0: x is the 24-bit residual in two planes (hi plane at x, lo plane x_lo_off bytes behind it)
+    uint16_t* xhi = reinterpret_cast<uint16_t*>(x) + (size_t)row * D;
+    uint8_t* xlo = reinterpret_cast<uint8_t*>(x) + x_lo_off + (size_t)row * D;
+    if constexpr (VEC == 4 && sizeof(T) == 2) {
+        if (x_lo_off) {
+            r.load_x24(xhi, xlo, lane);
+            if (d1) r.add_bf16(d1 + (size_t)row * D, lane);
+            if (d2) r.add_bf16(d2 + (size_t)row * D, lane);
+            if (WRITE_BACK && (d1 || d2)) r.store_x24(xhi, xlo, lane);
+            r.normalize(w, b, eps, lane);
+            r.store(y + (size_t)row * y_ld, lane);
+            return;
+        }
+    }
     if (WRITE_BACK && (nt_x & 2)) {  // LN1, A/B: every operand is a last use
         r.load_nt(x + (size_t)row * D, lane);
         if (d1) r.add_bf16_nt(d1 + (size_t)row * D, lane);
@@ -321,8 +366,8 @@ template <typename T, int VEC, int NT, bool WRITE_BACK>
 __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const bf16_t* __restrict__ d1,
                                                  const bf16_t* __restrict__ d2, T* __restrict__ y,
                                                  const float* __restrict__ w, const float* __restrict__ b, int rows,
-                                                 float eps, int y_ld, int split, int nt_x = 0) {
-    ln_body<T, VEC, NT, WRITE_BACK>(x, d1, d2, y, w, b, rows, eps, y_ld, split, nt_x);
+                                                 float eps, int y_ld, int split, int nt_x = 0, size_t x_lo_off = 0) {
+    ln_body<T, VEC, NT, WRITE_BACK>(x, d1, d2, y, w, b, rows, eps, y_ld, split, nt_x, x_lo_off);
 }
 // token assembly + pre-LN (modeling_clip.py:198-218, :641-651):
 // x[b*S+s] = LN_pre((s == 0 ? cls : patch[b*(S-1)+s-1]) + pos[s])
@@ -330,7 +375,7 @@ template <int VEC, int NT>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
                                                        const float* __restrict__ pos, float* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ b,
-                                                       int rows, int S, float eps) {
+                                                       int rows, int S, float eps, size_t x_lo_off = 0) {
     constexpr int D = 64 * VEC * NT;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -340,6 +385,12 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
     r.load(s == 0 ? cls : patch + ((size_t)bimg * (S - 1) + (s - 1)) * D, lane);
     r.add(pos + (size_t)s * D, lane);
     r.normalize(w, b, eps, lane);
+    if constexpr (VEC == 4) {
+        if (x_lo_off) {   // the residual stream as 24-bit floats in two planes (LnRow::store_x24)
+            r.store_x24(reinterpret_cast<uint16_t*>(x) + (size_t)row * D, reinterpret_cast<uint8_t*>(x) + x_lo_off + (size_t)row * D, lane);
+            return;
+        }
+    }
     r.store(x + (size_t)row * D, lane);
 }
 
@@ -355,6 +406,22 @@ __global__ void gather_rows_kernel(const T* __restrict__ src, T* __restrict__ ds
 }
 
 // dst[i * stride_rows][0 .. D) = src[i][0 .. D) with dst row pitch ld elements (the CLS queries of the last layer)
+// dst[i][:] (fp32) = row i * stride_rows of the 24-bit residual stream (two planes, LnRow::load_x24); D a multiple of 4
+__global__ void gather_rows_x24_kernel(const uint16_t* __restrict__ hi, const uint8_t* __restrict__ lo, float* __restrict__ dst, int n,
+                                       size_t stride_rows, int D) {
+    const size_t total = (size_t)n * (D / 4);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (D / 4), c = (i % (D / 4)) * 4, src = r * stride_rows * D + c;
+        const v2u h = *reinterpret_cast<const v2u*>(hi + src);
+        const uint32_t l = *reinterpret_cast<const uint32_t*>(lo + src);
+        v4f o;
+        o.x = __uint_as_float((h.x << 16) | ((l & 0xFFu) << 8));
+        o.y = __uint_as_float((h.x & 0xFFFF0000u) | (l & 0xFF00u));
+        o.z = __uint_as_float((h.y << 16) | ((l >> 8) & 0xFF00u));
+        o.w = __uint_as_float((h.y & 0xFFFF0000u) | ((l >> 16) & 0xFF00u));
+        *reinterpret_cast<v4f*>(dst + r * D + c) = o;
+    }
+}
 template <typename T>
 __global__ void scatter_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, size_t stride_rows, int D, size_t ld) {
     const int per = D * (int)sizeof(T) / 16;
@@ -574,7 +641,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
                                                    const bf16_t* __restrict__ delta2, const float* __restrict__ w,
                                                    const float* __restrict__ b, const float* __restrict__ proj,
                                                    float* __restrict__ out, int n, int S, int E, float eps,
-                                                   const int* __restrict__ row_of) {
+                                                   const int* __restrict__ row_of, size_t x_lo_off = 0) {
     constexpr int D = 64 * VEC * NT, IMG = 8;
     __shared__ float pooled[IMG][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -584,7 +651,14 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
         LnRow<VEC, NT> r;
         if (img < n) {
             const size_t row = row_of ? (size_t)row_of[img] : (size_t)img * S;  // vision: the CLS row; text: the EOS row
-            r.load(x + row * D, lane);
+            bool packed = false;
+            if constexpr (VEC == 4) {
+                if (x_lo_off) {   // 24-bit residual in two planes
+                    r.load_x24(reinterpret_cast<const uint16_t*>(x) + row * D, reinterpret_cast<const uint8_t*>(x) + x_lo_off + row * D, lane);
+                    packed = true;
+                }
+            }
+            if (!packed) r.load(x + row * D, lane);
             if (delta) r.add_bf16(delta + row * D, lane);
             if (delta2) r.add_bf16(delta2 + row * D, lane);
             r.normalize(w, b, eps, lane);

@@ -14,7 +14,7 @@ import torch
 from image_search_amd import synth
 from image_search_amd.clip import Model, PRECISION_BF16
 
-DEFAULTS = {"sched": 0, "ln_nt": 0, "split_tail": 1, "parts": 2, "part0_short": 0, "grid_cus": 0}
+DEFAULTS = {"sched": 0, "ln_nt": 0, "split_tail": 1, "parts": 2, "part0_short": 0, "grid_cus": 0, "x24": 1}
 
 
 def main():
@@ -61,6 +61,7 @@ def main():
     ref = outs[args[0]]
     res = {v: {"ms": [round(t, 3) for t in times[v]], "best": round(min(times[v]), 3),
                "bit_equal_to_first": bool((outs[v].view(np.uint32) == ref.view(np.uint32)).all()),
+               "max_diff_to_first_over_rms": float(np.abs(outs[v] - ref).max() / np.sqrt((ref.astype(np.float64) ** 2).mean())),
                "finite": bool(np.isfinite(outs[v]).all())} for v in args}
     print(json.dumps({"n": n, "reps": reps, "variants": res}))
 
