@@ -80,8 +80,11 @@ void mi_clip_free(mi_clip* m);
 /* `weights_path` may also be the file the reference's `-w` points at (server/src/server_arguments.rs:8-9): the Burn
  * named-MessagePack record `vision_model.mpk` that burn-import writes at build time (clip/build.rs:75-83).  Its field
  * names are those of the GENERATED module, which is not in the reference tree, so its tensors are mapped to the
- * Hugging Face names by shape and graph order (Linear weights transposed from Burn's [in, out]); an inventory that
- * does not match a CLIP vision tower exactly is refused (MI_ERR_UNSUPPORTED) with the inventory in the message.
+ * Hugging Face names by shape, module and graph order (Linear weights transposed from Burn's [in, out]).  Both the fused
+ * LayerNorm inventory and the DECOMPOSED one of the opset-16 graph the reference builds (clip/scripts/upgrade_opset.py:9-28:
+ * gamma / beta as bare constants, scalar and integer constants beside them) are recognised, with the linears as Linear modules
+ * or as bare MatMul + Add constants; leaves that cannot be a tower tensor are set aside and listed; an inventory that fits
+ * neither form is refused (MI_ERR_UNSUPPORTED) with the inventory in the message.
  * Untested against a real burn-import file (none exists offline); tools/make_synthetic_mpk.py writes the test files.
  *
  * mi_weights_list: the tensors either kind of file holds, as this library names them, one "name dtype [shape]" line
@@ -100,6 +103,13 @@ int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* nee
  *   "im2col_rows" 0 = the patch gather in 4P-byte runs instead of the LDS-staged rows form (A/B hook; same bits)
  *   "ln_nt"      bit 0 = LN1 writes the residual stream back with non-temporal stores, bit 1 = LN1's last-use loads are
  *                non-temporal (A/B hook, default 0; same bits, no measurable effect)
+ *   "x24"        1 (default) = the bf16 tower keeps its residual stream as 24-bit floats in two planes (16 significant
+ *                bits, 3 bytes per element: -14 % LayerNorm traffic, -1 % per forward, error against fp32 unchanged);
+ *                0 = fp32 rows.  Neither changes the fp32 parity path or the text tower
+ *   "sched"      how the two parts of a forward meet on the chip: 0 (default) = each on its own stream; 1 = all LDS-exclusive
+ *                kernels on one stream in a fixed alternation, LayerNorms on a side stream; 2 = blocks chained across the two
+ *                streams by events.  "part0_short" = n: the first part n images shorter; "grid_cus" = n: persistent grids capped
+ *                at n workgroups.  A/B hooks of round 4: same bits, all slower than the defaults
  *   "text_fast"  0 = a single text query takes the batched kernels instead of the skinny-GEMM path (text handles) */
 int mi_clip_set_option(mi_clip* m, const char* key, int value);
 
