@@ -250,7 +250,10 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s,
     }
     const uint64_t n_tiles = (t->rows + 63) / 64;
     const uint32_t blocks = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 4, (n_tiles + 3) / 4));
-    const uint32_t hb = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 8, (t->rows + 255) / 256);
+    // (a group multiplies the grid by its queries: fewer blocks per query then, or every one of 16 x 2048 blocks pays the
+    // histogram pick of the previous pass — a 2048-bin scan — for a few iterations of work)
+    const uint32_t hb1 = (uint32_t)std::min<uint64_t>((uint64_t)t->n_cu * 8, (t->rows + 255) / 256);
+    const uint32_t hb = std::max<uint32_t>(std::min<uint32_t>(hb1, (uint32_t)t->n_cu), (hb1 + gy - 1) / gy);
     uint32_t* flags = t->d_pref_flag;  // {candidate count, fallback, go}; not in d_sel: the selects below clear that
     uint32_t* key32 = t->d_pref_rows + PREF_CAP;
     uint32_t* count2 = t->d_sel + 6 * SEL_BINS;

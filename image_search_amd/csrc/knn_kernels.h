@@ -1034,14 +1034,14 @@ __global__ __launch_bounds__(256, 1) void knn_scan_coarse8_mfma_kernel(const uin
 
     // the digit fragments of this lane's column: column n of block b is digit d = n % 3 of query QPB b + n / 3
     v4i32 bf[NBLK][STEPS];
-    float S[NBLK], sqn[NBLK], rho[NBLK];
+    float Sq[NBLK], rho[NBLK];   // Sq = S / |q|: the digit scale over the query's norm (one multiplication per key instead of a division)
     int qcol[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
         const int qi = QPB * b + n / 3, d = n % 3;
         const bool live = n < 3 * QPB && qi < nq;
         qcol[b] = live && d == 0 ? qi : -1;
-        S[b] = live ? qs[4 * qi + 0] : 0.0f; sqn[b] = live ? qs[4 * qi + 1] : 1.0f; rho[b] = live ? qs[4 * qi + 2] : 0.0f;
+        Sq[b] = live ? qs[4 * qi + 0] / qs[4 * qi + 1] : 0.0f; rho[b] = live ? qs[4 * qi + 2] : 0.0f;
 #pragma unroll
         for (int t = 0; t < STEPS; ++t)
             bf[b][t] = live ? *reinterpret_cast<const v4i32*>(digits + ((size_t)qi * 3 + d) * DIM + (STEPS * g + t) * 16) : (v4i32){0, 0, 0, 0};
@@ -1099,6 +1099,11 @@ __global__ __launch_bounds__(256, 1) void knn_scan_coarse8_mfma_kernel(const uin
         const f32x4 sc = *reinterpret_cast<const f32x4*>(img + ROWS + 256 + 16 * g);
         const f32x4 cf = *reinterpret_cast<const f32x4*>(img + ROWS + 512 + 16 * g);
         const uint64_t row0 = (tile << 4) + 4 * g;
+        // per row, once for all queries: scale_r / |x_r| (a reciprocal square root and a product instead of a division and a
+        // square root per key: a few ulp, inside e0 like every other rounding of the coarse distance)
+        float rs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rs[j] = sc[j] * __builtin_amdgcn_rsqf(xs[j]);
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
             u32x4 key;
@@ -1108,8 +1113,7 @@ __global__ __launch_bounds__(256, 1) void knn_scan_coarse8_mfma_kernel(const uin
                 const int B = __builtin_amdgcn_update_dpp(0, A, 0x101, 0xF, 0xF, true);   // row_shl:1: lane n takes lane n + 1
                 const int C = __builtin_amdgcn_update_dpp(0, A, 0x102, 0xF, 0xF, true);   // row_shl:2
                 const float D = ((float)A * 16384.0f + (float)B * 128.0f) + (float)C;
-                const float dot = sc[j] * (S[b] * D);
-                const float upper = (1.0f - dot / (sqn[b] * sqrtf(xs[j]))) + (cf[j] * rho[b] + e0);
+                const float upper = (1.0f - (Sq[b] * D) * rs[j]) + (cf[j] * rho[b] + e0);
                 key[j] = xs[j] < 0.0f ? PREF_MARK : dist_to_u32(upper);
             }
             // rows beyond n_rows (a ragged last tile) write into the slack of the key array: cap is a multiple of 64 rows
