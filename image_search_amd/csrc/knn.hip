@@ -158,8 +158,10 @@ bool prefilter_applies(const mi_knn* t, uint32_t k) {
     const uint32_t width = t->prefilter == 2 ? 256u : 128u;  // whole 256-byte chunks per mirror row
     return t->prefilter && (k <= 64 || (k <= 4096 && t->select_path)) && t->dim % width == 0 && t->rows >= PREF_MIN_ROWS;
 }
+// sample_shift > 0 (matrix-pipe form only): every 2^shift-th 16-row tile's keys also go, compactly, to t->d_skeys [nq][sample_stride]
 template <int NCH>
-void launch_coarse8_batched(mi_knn* t, const uint8_t* m8, const float* d_q, float e0, uint32_t nq, uint32_t blocks, hipStream_t s) {
+void launch_coarse8_batched(mi_knn* t, const uint8_t* m8, const float* d_q, float e0, uint32_t nq, uint32_t blocks, hipStream_t s,
+                            int sample_shift = 0, uint64_t sample_stride = 0) {
     if constexpr (NCH == 12) {  // built for dim 768, the width of the reference's table (server/src/clip.rs:140-143)
         if (t->batch_stage1_mfma) {
             // the group's stage 1 on the matrix pipe: exact int8 dot products against the query cut into three 7-bit digits
@@ -171,7 +173,8 @@ void launch_coarse8_batched(mi_knn* t, const uint8_t* m8, const float* d_q, floa
     {                                                                                                                             \
         allow_lds(knn_scan_coarse8_mfma_kernel<NCH, NBLK, QPB>, LDS);                                                             \
         hipLaunchKernelGGL((knn_scan_coarse8_mfma_kernel<NCH, NBLK, QPB>), dim3(grid), dim3(256), LDS, s, m8, t->d_xx, t->d_scale8, \
-                           t->d_cfac8, t->rows, t->d_digits, t->d_qs, (int)nq, e0, t->d_keys32, (uint64_t)t->cap);                \
+                           t->d_cfac8, t->rows, t->d_digits, t->d_qs, (int)nq, e0, t->d_keys32, (uint64_t)t->cap,                 \
+                           sample_shift ? t->d_skeys : (uint32_t*)nullptr, sample_shift, sample_stride);                          \
     }
             if (nq <= 5) MI_C8M(1, 5)
             else if (nq <= 10) MI_C8M(2, 5)
@@ -222,6 +225,18 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s,
     ensure(t, (void**)&t->d_pref_keys, &t->pref_keys_cap, (size_t)4096 * gy, sizeof(uint64_t));
     ensure(t, (void**)&t->d_pref_flag, &t->pref_flag_cap, (size_t)4 * gy, sizeof(uint32_t));
     const bool bytes = t->prefilter == 2;
+    // The threshold from a SAMPLE of the keys (byte mirror, k <= 64): stage 1 also writes the keys of every 8th tile compactly,
+    // the three histogram passes read that eighth, and the collect pass filters ALL keys against the sample's k-th smallest
+    // upper bound — which is >= the k-th smallest over all rows, hence a valid (looser) threshold: a few times more candidates
+    // for stage 2 (hundreds instead of tens at k = 10), three quarters of the select's traffic gone.  Tiles of 64 rows for one
+    // query, of 16 rows for a group on the matrix pipe; the old vector-ALU group kernel does not sample.
+    const uint32_t tile_rows = (nq_batch && t->batch_stage1_mfma) ? 16 : 64;
+    const uint64_t n_tiles_s = (t->rows + tile_rows - 1) / tile_rows;
+    int sample_shift = (bytes && t->pref_sample && k <= 64 && (nq_batch == 0 || t->batch_stage1_mfma)) ? 3 : 0;
+    uint64_t n_sample = ((n_tiles_s + (1u << sample_shift) - 1) >> sample_shift) * tile_rows;
+    if (sample_shift && (t->rows >> sample_shift) < std::max<uint64_t>(4096, 64ull * k)) { sample_shift = 0; n_sample = 0; }   // too small a table: the sample would be no guide
+    const uint64_t sample_stride = sample_shift ? (n_sample + 63) / 64 * 64 : 0;
+    if (sample_shift) ensure(t, (void**)&t->d_skeys, &t->skeys_cap, (size_t)sample_stride * gy, sizeof(uint32_t));
     const size_t mirror_elems = bytes ? ((size_t)t->cap * t->dim + 1) / 2 : (size_t)t->cap * t->dim;  // in uint16 units
     t->mirror_rows = std::min(t->mirror_rows, t->rows);
     if (bytes && t->g8_ready && t->rows >= 4 * std::max<uint64_t>(t->g8_rows, 1)) t->g8_ready = false;  // the table has grown 4x since the
@@ -267,6 +282,12 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s,
     if (bytes) {
         uint8_t* m8 = reinterpret_cast<uint8_t*>(t->d_mirror);
         const uint32_t* keys_q = t->d_keys32;   // query y: + y * cap (QGroup)
+        // what the histogram passes read: every key, or the sample (its own stride between the queries of a group)
+        const uint32_t* keys_h = sample_shift ? t->d_skeys : keys_q;
+        const uint64_t n_h = sample_shift ? n_sample : t->rows;
+        QGroup qgh = qg;
+        if (sample_shift && gy > 1) qgh.keys = sample_stride;
+        const uint32_t hbh = sample_shift ? std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>(hb, (n_h + 1023) / 1024)) : hb;
         switch (t->dim / 64) {
 #define MI_CASE(NCH)                                                                                                     \
     case NCH:                                                                                                            \
@@ -279,15 +300,17 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s,
         }                                                                                                                \
         if (nq_batch == 0 && t->coarse_ring == 8)  /* 169 VGPRs: two workgroups per CU are resident, launch exactly those */ \
             hipLaunchKernelGGL((knn_scan_coarse8_kernel<NCH, 8>), dim3(std::min(blocks, (uint32_t)t->n_cu * ring8_bpc)), dim3(256), 0, s, m8, t->d_xx, t->d_scale8, \
-                               t->d_cfac8, t->d_g8, t->rows, d_q, e0, t->d_keys32, t->d_rho8);                           \
+                               t->d_cfac8, t->d_g8, t->rows, d_q, e0, t->d_keys32, t->d_rho8,                            \
+                               sample_shift ? t->d_skeys : (uint32_t*)nullptr, sample_shift);                            \
         else if (nq_batch == 0)                                                                                          \
             hipLaunchKernelGGL((knn_scan_coarse8_kernel<NCH, 4>), dim3(blocks), dim3(256), 0, s, m8, t->d_xx, t->d_scale8, \
-                               t->d_cfac8, t->d_g8, t->rows, d_q, e0, t->d_keys32, t->d_rho8);                           \
+                               t->d_cfac8, t->d_g8, t->rows, d_q, e0, t->d_keys32, t->d_rho8,                            \
+                               sample_shift ? t->d_skeys : (uint32_t*)nullptr, sample_shift);                            \
         else                                                                                                             \
-            launch_coarse8_batched<NCH>(t, m8, d_q, e0, nq_batch, blocks, s);                                            \
+            launch_coarse8_batched<NCH>(t, m8, d_q, e0, nq_batch, blocks, s, sample_shift, sample_stride);               \
         for (int p = 0; p < 3; ++p)                                                                                      \
-            hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hb, gy), dim3(256), 0, s, keys_q, t->rows, k, p, t->d_sel, states, \
-                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, qg, 0);     \
+            hipLaunchKernelGGL(knn_select_hist_kernel, dim3(hbh, gy), dim3(256), 0, s, keys_h, n_h, k, p, t->d_sel, states, \
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, qgh, 0);    \
         hipLaunchKernelGGL(knn_prefilter_collect8_kernel, dim3(hb, gy), dim3(256), 0, s, keys_q, t->d_cfac8, t->rows, k, \
                            t->d_sel, states, t->d_rho8, e0, PREF_CAP, t->d_pref_rows, flags, qg);                        \
         hipLaunchKernelGGL((knn_rescore_kernel<NCH>), dim3(t->n_cu * (gy > 1 ? 2 : 8), gy), dim3(256), 0, s, t->table, d_q, \
@@ -630,7 +653,7 @@ void mi_knn_free(mi_knn* t) {
     for (void* p : {(void*)t->table, (void*)t->d_q, (void*)t->d_cand, (void*)t->d_tmp, (void*)t->d_keys,
                     (void*)t->d_idx, (void*)t->d_dist, (void*)t->d_keys32, (void*)t->d_sel, (void*)t->d_mirror,
                     (void*)t->d_xx, (void*)t->d_pref_rows, (void*)t->d_pref_keys, (void*)t->d_pref_flag, (void*)t->d_scale8,
-                    (void*)t->d_cfac8, (void*)t->d_rho8, (void*)t->d_g8, (void*)t->d_digits, (void*)t->d_qs})
+                    (void*)t->d_cfac8, (void*)t->d_rho8, (void*)t->d_g8, (void*)t->d_digits, (void*)t->d_qs, (void*)t->d_skeys})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : t->pref_ev)
         if (e) (void)hipEventDestroy(e);
@@ -658,6 +681,10 @@ int mi_knn_set_option(mi_knn* t, const char* key, int value) {
             }
             if (value != t->prefilter) pref_reset(t);
             t->prefilter = value;
+        } else if (k == "prefilter_sample") {
+            // 1 (default): k <= 64 over the byte mirror takes the collect threshold from a sample of the stage-1 keys (an eighth
+            // of the select's reads, a few times more rows for stage 2); 0: from all keys.  Same answers either way.
+            t->pref_sample = value != 0;
         } else if (k == "batch_stage1") {
             // 1 (default): the shared stage 1 of a group of queries on the matrix pipe (int8 MFMA, knn_scan_coarse8_mfma_kernel);
             // 0: the vector-ALU form (knn_scan_coarse8_batched_kernel).  Same answers either way.
@@ -669,7 +696,7 @@ int mi_knn_set_option(mi_knn* t, const char* key, int value) {
             pref_reset(t);
             t->pref_adaptive = value != 0;
         } else {
-            fail(MI_ERR_INVALID, "unknown option '%s' (known: prefilter, prefilter_adaptive, batch_stage1)", key);
+            fail(MI_ERR_INVALID, "unknown option '%s' (known: prefilter, prefilter_adaptive, prefilter_sample, batch_stage1)", key);
         }
     });
 }

@@ -771,7 +771,11 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_kernel(const uint8_t*
                                                                const float* __restrict__ scale, const float* __restrict__ cfac,
                                                                const float* __restrict__ gch, uint64_t n_rows,
                                                                const float* __restrict__ q, float e0,
-                                                               uint32_t* __restrict__ all_keys, float* __restrict__ rho_out) {
+                                                               uint32_t* __restrict__ all_keys, float* __restrict__ rho_out,
+                                                               uint32_t* __restrict__ sample_keys = nullptr, int sample_shift = 0) {
+    // sample_keys (nullable): the keys of every 2^sample_shift-th tile once more, compactly — the threshold of the collect
+    // pass is then taken from this sample (its k-th smallest key is >= the k-th smallest of all rows: a valid, looser
+    // threshold), and the three histogram passes read an eighth of the keys
     static_assert(NCH % 4 == 0, "rows of whole 256-byte chunks of bytes");
     constexpr int DIM = NCH * 64, U = NCH / 4;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -837,6 +841,16 @@ __global__ __launch_bounds__(256, 2) void knn_scan_coarse8_kernel(const uint8_t*
             const float dot = scale[r] * (mydot - qsum128);
             const float upper = (1.0f - dot / (sq * sqrtf(s))) + (cfac[r] * rho + e0);
             all_keys[r] = s < 0.0f ? PREF_MARK : dist_to_u32(upper);
+        }
+        if (sample_keys && (tile & ((1ull << sample_shift) - 1)) == 0) {
+            uint32_t key = 0xFFFFFFFFu;   // a row beyond the table ranks last in the sample
+            if (r < n_rows) {
+                const float s = xx[r];
+                const float dot = scale[r] * (mydot - qsum128);
+                const float upper = (1.0f - dot / (sq * sqrtf(s))) + (cfac[r] * rho + e0);
+                key = s < 0.0f ? PREF_MARK : dist_to_u32(upper);
+            }
+            sample_keys[((tile >> sample_shift) << 6) + lane] = key;
         }
     }
 }
@@ -1021,7 +1035,9 @@ __global__ __launch_bounds__(256, 1) void knn_scan_coarse8_mfma_kernel(const uin
                                                                      const float* __restrict__ scale, const float* __restrict__ cfac,
                                                                      uint64_t n_rows, const int8_t* __restrict__ digits,
                                                                      const float* __restrict__ qs, int nq, float e0,
-                                                                     uint32_t* __restrict__ all_keys, uint64_t key_stride) {
+                                                                     uint32_t* __restrict__ all_keys, uint64_t key_stride,
+                                                                     uint32_t* __restrict__ sample_keys = nullptr, int sample_shift = 0,
+                                                                     uint64_t sample_stride = 0) {
     static_assert(NCH % 4 == 0 && 3 * QPB <= 16, "rows of whole 256-byte chunks; a block's digit columns fit 16");
     constexpr int DIM = NCH * 64, STEPS = DIM / 64, NDMA = DIM / 64, TILE = c8m_tile_bytes(DIM), ROWS = 16 * DIM;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1117,8 +1133,16 @@ __global__ __launch_bounds__(256, 1) void knn_scan_coarse8_mfma_kernel(const uin
                 key[j] = xs[j] < 0.0f ? PREF_MARK : dist_to_u32(upper);
             }
             // rows beyond n_rows (a ragged last tile) write into the slack of the key array: cap is a multiple of 64 rows
-            if (qcol[b] >= 0) *reinterpret_cast<u32x4*>(all_keys + (size_t)qcol[b] * key_stride + row0) = key;
-            else asm volatile("" ::"v"(key));
+            if (qcol[b] >= 0) {
+                *reinterpret_cast<u32x4*>(all_keys + (size_t)qcol[b] * key_stride + row0) = key;
+                // every 2^sample_shift-th tile once more, compactly (knn_scan_coarse8_kernel: the sample the threshold is taken from);
+                // a row beyond the table must rank LAST there (its key above is arithmetic on zero-filled scalars)
+                if (sample_keys && (tile & ((1ull << sample_shift) - 1)) == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) key[j] = row0 + j < n_rows ? key[j] : 0xFFFFFFFFu;
+                    *reinterpret_cast<u32x4*>(sample_keys + (size_t)qcol[b] * sample_stride + ((tile >> sample_shift) << 4) + 4 * g) = key;
+                }
+            } else asm volatile("" ::"v"(key));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this image's reads have retired before it is refilled two tiles on
         buf = buf == 2 ? 0 : buf + 1;
