@@ -494,3 +494,38 @@ def test_a_group_in_which_some_queries_fall_back_and_others_do_not(built, k):
         assert np.array_equal(got[0][u], want[u][0]), u
         assert np.array_equal(got[1][u].view(np.uint32), want[u][1].view(np.uint32)), u
     t.close()
+
+
+@pytest.mark.parametrize("k", [1, 10, 64])
+def test_the_sampled_threshold_gives_the_same_answers_even_when_the_sample_misleads(built, k):
+    """"prefilter_sample" (round 4): for k <= 64 the collect threshold is the k-th smallest upper bound of every 8th tile's keys
+    — valid because the k-th smallest of a subset is never below the k-th smallest of the whole, looser when the sample is
+    unrepresentative.  Here it is as unrepresentative as it gets: every row of a sampled tile (64-row tiles for one query,
+    16-row tiles for a group: rows whose index is 0..63 mod 512 cover both) points AWAY from the queries, every near row sits in
+    a tile the sample never sees.  Same ids and distance bits as the single pass, for one query and for a group, with the
+    option on and off; with it on, stage 2 re-evaluates more rows."""
+    rng = np.random.default_rng(77 + k)
+    n = N + 777
+    qs = rng.standard_normal((5, DIM)).astype(np.float32)
+    rows = rng.standard_normal((n, DIM)).astype(np.float32)
+    idx = np.arange(n)
+    sampled = (idx % 512) < 64
+    rows[sampled] = -qs[0] + 0.3 * rows[sampled]                     # far from query 0 (and from its neighbours)
+    near = np.flatnonzero(~sampled)[rng.permutation((~sampled).sum())[:200]]
+    rows[near] = qs[0] + 0.2 * rows[near]                             # the true neighbours of query 0: never in the sample
+    t = EmbeddingTable(DIM, 0)
+    t.insert(rows)
+    want = t.knn(qs, k)                                               # prefilter off
+    t.set_option("prefilter", 2)
+    cands = {}
+    for flag in (0, 1):
+        t.set_option("prefilter_sample", flag)
+        got1 = t.knn(qs[0], k)
+        cands[flag], fell_back = t.prefilter_stats()
+        assert not fell_back
+        assert np.array_equal(got1[0], want[0][0]) and np.array_equal(got1[1].view(np.uint32), want[1][0].view(np.uint32)), flag
+        got = t.knn(qs, k)                                            # a group of 5
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32)), flag
+    assert set(want[0][0].tolist()) <= set(near.tolist())             # the answer is made of rows the sample never saw
+    assert cands[1] >= cands[0] >= k
+    t.close()
