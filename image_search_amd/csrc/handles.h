@@ -127,7 +127,7 @@ struct mi_knn {
     int8_t* d_digits = nullptr;     // [8][3][dim]: the queries of a group as three signed 7-bit digits
     float* d_qs = nullptr;          // [8][4]: {digit scale S, |q|, rho, -}
     size_t digits_cap = 0, qs_cap = 0;
-    bool pref_sample = true;        // k <= 64 over the byte mirror: the collect threshold from a sample of the stage-1 keys (option "prefilter_sample")
+    int pref_sample = 1;            // k <= 64 over the byte mirror: the collect threshold from a sample of the stage-1 keys — 1: for groups of queries, 2: for single queries too, 0: never (option "prefilter_sample")
     uint32_t* d_skeys = nullptr;    // [queries of a group][sample rows]: the keys of every 8th tile, compact
     size_t skeys_cap = 0;
     uint64_t mirror_rows = 0;

@@ -232,10 +232,14 @@ uint32_t* prefilter_pass(mi_knn* t, const float* d_q, uint32_t k, hipStream_t s,
     // query, of 16 rows for a group on the matrix pipe; the old vector-ALU group kernel does not sample.
     const uint32_t tile_rows = (nq_batch && t->batch_stage1_mfma) ? 16 : 64;
     const uint64_t n_tiles_s = (t->rows + tile_rows - 1) / tile_rows;
-    int sample_shift = (bytes && t->pref_sample && k <= 64 && (nq_batch == 0 || t->batch_stage1_mfma)) ? 3 : 0;
+    // (groups only by default: for ONE query the 45 us of histogram reads it saves go into the larger stage 2 — measured equal at
+    // k = 10, 2 % slower at k = 64; "prefilter_sample" = 2 samples for single queries too)
+    int sample_shift = (bytes && t->pref_sample && k <= 64 && ((nq_batch >= 2 && t->batch_stage1_mfma) || (nq_batch == 0 && t->pref_sample >= 2))) ? 3 : 0;
     uint64_t n_sample = ((n_tiles_s + (1u << sample_shift) - 1) >> sample_shift) * tile_rows;
     if (sample_shift && (t->rows >> sample_shift) < std::max<uint64_t>(4096, 64ull * k)) { sample_shift = 0; n_sample = 0; }   // too small a table: the sample would be no guide
-    const uint64_t sample_stride = sample_shift ? (n_sample + 63) / 64 * 64 : 0;
+    // sized by the table's CAPACITY, not its rows: a table that grows by a chunk per step (the pipeline) must not reallocate
+    // the sample — and wait for the searches in flight — every other query
+    const uint64_t sample_stride = sample_shift ? ((((t->cap + tile_rows - 1) / tile_rows + (1u << sample_shift) - 1) >> sample_shift) * tile_rows + 63) / 64 * 64 : 0;
     if (sample_shift) ensure(t, (void**)&t->d_skeys, &t->skeys_cap, (size_t)sample_stride * gy, sizeof(uint32_t));
     const size_t mirror_elems = bytes ? ((size_t)t->cap * t->dim + 1) / 2 : (size_t)t->cap * t->dim;  // in uint16 units
     t->mirror_rows = std::min(t->mirror_rows, t->rows);
@@ -682,9 +686,11 @@ int mi_knn_set_option(mi_knn* t, const char* key, int value) {
             if (value != t->prefilter) pref_reset(t);
             t->prefilter = value;
         } else if (k == "prefilter_sample") {
-            // 1 (default): k <= 64 over the byte mirror takes the collect threshold from a sample of the stage-1 keys (an eighth
-            // of the select's reads, a few times more rows for stage 2); 0: from all keys.  Same answers either way.
-            t->pref_sample = value != 0;
+            // 1 (default): a GROUP of queries, k <= 64, over the byte mirror takes the collect threshold from a sample of the stage-1
+            // keys (an eighth of the select's reads, a few times more rows for stage 2); 2: single queries too; 0: always from all
+            // keys.  Same answers either way.
+            if (value < 0 || value > 2) fail(MI_ERR_INVALID, "prefilter_sample must be 0, 1 or 2");
+            t->pref_sample = value;
         } else if (k == "batch_stage1") {
             // 1 (default): the shared stage 1 of a group of queries on the matrix pipe (int8 MFMA, knn_scan_coarse8_mfma_kernel);
             // 0: the vector-ALU form (knn_scan_coarse8_batched_kernel).  Same answers either way.

@@ -191,9 +191,10 @@ int mi_knn_set_base(mi_knn* t, uint64_t base);
  * "batch_stage1" = 1 (default) / 0: how a GROUP of queries (mi_knn_search with nq >= 2, mi_knn_search_batched_device) runs its
  * shared stage 1 over the byte mirror: 1 on the matrix pipe (any group size up to 16; HBM-bound), 0 on the vector ALU
  * (groups of 8 / 4 / 2; the round-3 form, kept for A/B).  Same answers either way.
- * "prefilter_sample" = 1 (default) / 0: with the byte mirror and k <= 64 the collect threshold is the k-th smallest upper bound
- * of a SAMPLE of the stage-1 keys (every 8th tile): a valid, looser threshold — a few times more rows for stage 2, an eighth of
- * the select's reads (what a group of queries gains most from).  0: the threshold over all keys.  Same answers either way.
+ * "prefilter_sample" = 1 (default) / 2 / 0: with the byte mirror and k <= 64 a GROUP of queries takes its collect threshold from the
+ * k-th smallest upper bound of a SAMPLE of the stage-1 keys (every 8th tile): a valid, looser threshold — a few times more rows
+ * for stage 2, an eighth of the select's reads (16 queries per call: - 11 %).  2: single queries too (measured equal at k = 10,
+ * 2 % slower at k = 64).  0: always the threshold over all keys.  Same answers either way.
  * "prefilter_adaptive" = 1 (default) / 0: the two-stage search watches itself — candidate counts and fallbacks are read
  * back asynchronously; after two consecutive fallbacks (more than 2^22 candidates) the next 64 single-query searches run
  * the single pass alone (what such a corpus would pay anyway, without stage 1 on top), then stage 1 is probed again with

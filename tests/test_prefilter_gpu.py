@@ -518,7 +518,7 @@ def test_the_sampled_threshold_gives_the_same_answers_even_when_the_sample_misle
     want = t.knn(qs, k)                                               # prefilter off
     t.set_option("prefilter", 2)
     cands = {}
-    for flag in (0, 1):
+    for flag in (0, 2):                                               # 2: single queries sample too (1, the default: groups only)
         t.set_option("prefilter_sample", flag)
         got1 = t.knn(qs[0], k)
         cands[flag], fell_back = t.prefilter_stats()
@@ -527,5 +527,5 @@ def test_the_sampled_threshold_gives_the_same_answers_even_when_the_sample_misle
         got = t.knn(qs, k)                                            # a group of 5
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32)), flag
     assert set(want[0][0].tolist()) <= set(near.tolist())             # the answer is made of rows the sample never saw
-    assert cands[1] >= cands[0] >= k
+    assert cands[2] >= cands[0] >= k
     t.close()
