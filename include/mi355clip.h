@@ -19,6 +19,10 @@
  *   - "host" pointers are ordinary memory; "_device" entry points take HIP
  *     device pointers on the handle's device and a hipStream_t passed as void*
  *     (NULL = the handle's own stream) and do not synchronise the stream.
+ *     NB: NULL is NOT "the device's NULL stream": a device buffer that another stream is still writing — the legacy default
+ *     stream of a framework included, which is what PyTorch's current stream is unless one is set — must be complete
+ *     before it is handed over with NULL, or be handed over with the stream that produces it (a dev tool of this
+ *     repository got this wrong for three rounds: tools/knn_prefilter_soak.py).
  *     The work a handle enqueues runs in CALL ORDER whichever streams the calls
  *     name: every entry point first makes its stream wait (an event, no host
  *     block) for what the handle enqueued before.  So embed_device(stream A) ->

@@ -131,6 +131,7 @@ def test_more_candidates_than_stage_two_accepts_fall_back_to_the_single_pass(bui
     t = EmbeddingTable(DIM, 0)
     t.reserve(4_400_000)
     x = base[None, :].repeat(100_000, 1).contiguous()  # exact duplicates: one coarse key for all of them
+    torch.cuda.synchronize()   # torch's NULL stream means "the handle's own stream" to insert_device: x must be complete first
     for i in range(44):
         t.insert_device(x.data_ptr(), 100_000, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
@@ -167,6 +168,7 @@ def test_other_row_widths(built, dim):
     t = EmbeddingTable(dim, 0)
     n = 270_000
     x = torch.randn((n, dim), device="cuda", generator=gen)
+    torch.cuda.synchronize()   # (insert_device runs on the handle's own stream when handed torch's NULL stream)
     t.insert_device(x.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     for j, k in enumerate((1, 10, 64, 300)):
@@ -361,6 +363,7 @@ def test_repeated_fallbacks_switch_stage_one_off_for_a_while_and_probe_again(bui
     t = EmbeddingTable(DIM, 0)
     t.reserve(4_400_000)
     x = base[None, :].repeat(100_000, 1).contiguous()
+    torch.cuda.synchronize()
     for i in range(44):
         t.insert_device(x.data_ptr(), 100_000, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
@@ -471,6 +474,7 @@ def test_a_group_in_which_some_queries_fall_back_and_others_do_not(built, k):
     t.reserve(4_600_000)
     t.insert_synthetic(33, 0, N)
     x = base[None, :].repeat(100_000, 1).contiguous()
+    torch.cuda.synchronize()   # (insert_device below runs on the handle's own stream: x must be complete first)
     for i in range(43):
         t.insert_device(x.data_ptr(), 100_000, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()

@@ -36,6 +36,12 @@ ok = True
 for kind in ("iid", "heavy tails", "outlier channels", "clusters", "unit norm, small offsets"):
     x = corpus(kind)
     t = EmbeddingTable(768, 0)
+    # torch's default stream is the NULL stream, and a NULL stream means "the handle's own stream" to insert_device — which is
+    # not ordered behind torch's kernels: wait for the corpus first.  (Through round 3 this wait was missing: the table could
+    # receive the PREVIOUS corpus's bytes from the reused allocation; ids and distance bits were compared on whatever the table
+    # held, so the zero-mismatch results stand, but the candidate counts of the "clusters" / "unit norm" rows of older
+    # profiles are those of stale iid-like data in some runs.)
+    torch.cuda.synchronize()
     t.insert_device(x.data_ptr(), N, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     for mode in (1, 2):

@@ -43,6 +43,7 @@ def fill(table, kind, n, q, gen):
             x = centres[c] + 0.1 * x
         elif kind == "duplicates" and lo < n // 2:
             x = centres[3][None, :].repeat(m, 1).contiguous()
+        torch.cuda.synchronize()   # torch's NULL stream = "the handle's own stream" for insert_device: the block must be complete first
         table.insert_device(x.data_ptr(), m, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
     return centres
