@@ -1020,6 +1020,12 @@ __device__ __forceinline__ void glds16_buf(rsrc_t r, uint32_t voff, uint32_t sof
 //   (group 1 in front of its barrier, group 0 behind its own = the same instance); its 16 stores and
 //   the bias DMA stay in the queue for the next two waits (vmcnt(25)).
 //   A four-phase form (16 MFMAs per barrier interval, 8 barriers per K tile) measured 2-3 % slower.
+// PP_CLOCK_BEGIN / PP_CLOCK_END: hooks of the diagnostic build of tools/probe/gemm_pp_sweep.hip (-DPP_CLOCK: the shader
+// clock the chip holds under this kernel, MI355X_MICROARCH.md 'DVFS give-back' item 6); empty here.
+#ifndef PP_CLOCK_BEGIN
+#define PP_CLOCK_BEGIN
+#define PP_CLOCK_END
+#endif
 template <int EPI, typename TO>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ X,
                                                               const bf16_t* __restrict__ W,
@@ -1035,6 +1041,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
     const int nt = N / 256;
     const int G = gridDim.x;
     const int lb = (int)xcd_remap(blockIdx.x, G);
+    PP_CLOCK_BEGIN
 
     const uint32_t Kb = (uint32_t)K * 2;
     const rsrc_t xr = make_rsrc(X, (uint32_t)M * Kb);
@@ -1281,6 +1288,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    PP_CLOCK_END
 #undef PP_QUADRANT
 #undef PP_BAR
 }

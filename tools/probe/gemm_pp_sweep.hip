@@ -2,11 +2,17 @@
 // back-to-back rate (20 launches between two events) and as ISOLATED launches (one launch between two events, the stream
 // drained around it, a 512 MB copy in between so that the operands come from HBM as they do in the tower).
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off tools/probe/gemm_pp_sweep.hip -o tools/probe/gemm_pp_sweep
+//   ... -DPP_CLOCK -o tools/probe/gemm_pp_clock : the shader clock the chip holds under the kernel (random and all-zero operands)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include "../../include/mi355clip.h"
+#ifdef PP_CLOCK   // diagnostic build: the shader clock held under the kernel = d(s_memtime) / d(s_memrealtime) x 100 MHz per workgroup
+__device__ unsigned long long* pp_clock_buf;
+#define PP_CLOCK_BEGIN const unsigned long long c0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime();
+#define PP_CLOCK_END if (threadIdx.x == 0) { pp_clock_buf[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - c0_; pp_clock_buf[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0_; }
+#endif
 #include "../../image_search_amd/csrc/vit_kernels.h"
 using namespace mi;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -35,6 +41,43 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 151552));
     CK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 151552));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+#ifdef PP_CLOCK
+    // per shape: >= 2 s of back-to-back launches, then the clock of the LAST launch (median over workgroups), on the random
+    // operands and on all-zero ones (the clock the chip would hold if the MFMAs cost no energy)
+    unsigned long long* cbuf; CK(hipMalloc(&cbuf, 256 * 2 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(pp_clock_buf), &cbuf, sizeof(cbuf)));
+    for (int zeros = 0; zeros < 2; ++zeros) {
+        if (zeros) { CK(hipMemset(X, 0, Mmax * 4096 * 2)); CK(hipMemset(W, 0, (size_t)4096 * 4096 * 2)); }
+        for (size_t Mrows : {(size_t)32896, (size_t)65792}) {
+            const size_t Mp = (Mrows + 255) / 256 * 256;
+            for (auto& s : shapes) {
+                const int n_tiles = (int)((Mp / 256) * (s.N / 256)), grid = std::min(n_tiles * 4, 256);
+                const int left = n_tiles % grid;
+                const int n_full = (split && left > 0 && left * 4 <= grid) ? n_tiles - left : n_tiles;
+                auto launch = [&] {
+                    if (s.N == 4096) hipLaunchKernelGGL(k2, dim3(grid), dim3(512), 151552, 0, X, W, bias, (void*)O, (int)Mp, s.N, s.K, s.N, n_tiles, n_full, 0);
+                    else hipLaunchKernelGGL(k1, dim3(grid), dim3(512), 151552, 0, X, W, bias, (void*)O, (int)Mp, s.N, s.K, s.N, n_tiles, n_full, 0);
+                };
+                float total = 0, ms = 0; int launches = 0;
+                while (total < 2000.0f) {
+                    CK(hipEventRecord(e0));
+                    for (int i = 0; i < 200; ++i) launch();
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    total += ms; launches += 200;
+                }
+                unsigned long long h[512]; CK(hipMemcpy(h, cbuf, sizeof(h), hipMemcpyDeviceToHost));
+                double ghz[256]; for (int i = 0; i < grid; ++i) ghz[i] = (double)h[2 * i] / (double)h[2 * i + 1] * 0.1;
+                std::sort(ghz, ghz + grid);
+                const double us = ms / 200 * 1e3;
+                printf("%s M=%zu %s: %.1f us = %.0f TFLOP/s, shader clock %.3f GHz (median of %d workgroups; min %.3f max %.3f) -> %.1f %% of the MFMA rate at THAT clock\n",
+                       zeros ? "zeros " : "random", Mrows, s.name, us, 2.0 * Mrows * s.N * s.K / us / 1e6, ghz[grid / 2], grid, ghz[0], ghz[grid - 1],
+                       100.0 * (2.0 * Mrows * s.N * s.K / us / 1e6) / (256 * 4 * 1024 * ghz[grid / 2] / 1e3));
+            }
+        }
+    }
+    return 0;
+#endif
     for (size_t Mrows : {(size_t)32768, (size_t)32896, (size_t)65536, (size_t)65792}) {   // whole rounds of tiles (no tail) beside the tower's row counts
         const size_t Mp = (Mrows + 255) / 256 * 256;
         for (auto& s : shapes) {
