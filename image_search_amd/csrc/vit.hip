@@ -294,8 +294,11 @@ void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out
             // a short last round (<= a quarter of the CUs busy) is cut into quadrant tasks
             const int left = n_tiles % grid;
             const int n_full = (m->split_tail && left > 0 && left * 4 <= grid) ? n_tiles - left : n_tiles;
+            const int nt = N / 256;
+            auto fits = [&](int np) { return np > 0 && nt > np && nt % np == 0; };
+            const int order = fits(m->gemm_order) ? m->gemm_order : (m->gemm_order > 0 && fits(4)) ? 4 : 0;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, (int)Mp, N,
-                               K, ldo, n_tiles, n_full, 0);
+                               K, ldo, n_tiles, n_full, order);
             HIP_CHECK(hipGetLastError());
             return;
         }
@@ -818,6 +821,10 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         if (k == "full_last") m->full_last = value != 0;
         else if (k == "attn_shift") m->attn_shift = value != 0;
         else if (k == "split_tail") m->split_tail = value != 0;
+        else if (k == "gemm_order") {
+            if (value < 0 || value > 16) fail(MI_ERR_INVALID, "gemm_order must be 0..16");
+            m->gemm_order = value;
+        }
         else if (k == "im2col_rows") m->im2col_rows = value != 0;
         else if (k == "text_fast") m->text_fast = value != 0;
         else if (k == "ln_nt") m->ln_nt = value & 3;
@@ -853,7 +860,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, im2col_rows, ln_nt, sched, x24, part0_short, grid_cus, text_fast, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, gemm_order, im2col_rows, ln_nt, sched, x24, part0_short, grid_cus, text_fast, max_batch, parts)", key);
     });
 }
 
@@ -879,6 +886,7 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         if (const char* e = std::getenv("MI_CLIP_FULL_LAST")) m->full_last = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_CLIP_ATTN")) m->attn_ver = std::atoi(e) == 1 ? 1 : 2;  // fixed at load: decides the q scale
         if (const char* e = std::getenv("MI_GEMM_SPLIT")) m->split_tail = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MI_GEMM_ORDER")) m->gemm_order = std::max(0, std::min(16, std::atoi(e)));
         if (const char* e = std::getenv("MI_CLIP_IM2COL")) m->im2col_rows = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_CLIP_LN_NT")) m->ln_nt = std::atoi(e) & 3;
         if (const char* e = std::getenv("MI_CLIP_X24")) m->x24 = std::atoi(e) != 0;
@@ -1165,6 +1173,7 @@ int mi_op_linear(int device, int precision, int epilogue, const float* x, const 
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         mm.n_cu = prop.multiProcessorCount;
         if (const char* e = std::getenv("MI_OP_GRID")) mm.n_cu = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("MI_OP_GEMM_ORDER")) mm.gemm_order = std::max(0, std::min(16, std::atoi(e)));
         switch (epilogue) {
             case EPI_STORE_F32: gemm<EPI_STORE_F32>(&mm, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;
             case EPI_BIAS: gemm<EPI_BIAS>(&mm, dx, dw, db, dout, m_rows, n, k, n, nullptr); break;

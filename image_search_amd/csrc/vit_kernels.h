@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias,
                                                               void* __restrict__ out, int M, int N, int K, int ldo,
-                                                              int n_tiles, int n_full, int /*unused*/) {
+                                                              int n_tiles, int n_full, int order) {
     static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU, "the persistent form stores bf16 with bias");
     static_assert(sizeof(TO) == 2, "bf16 output");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 128 KiB staging + 18 KiB patches + 2 KiB bias
@@ -1099,10 +1099,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
     // position in the flattened (tile, K tile) stream of this workgroup
     struct Pos { uint32_t xs, ws; int kt, tile, tm, tn; bool ok; };
     const int nk = K / 64;
+    // visit index -> tile.  order == 0: row-major (an XCD's 32 concurrent tiles = 32 / nt row panels x ALL nt weight tiles:
+    // every XCD streams the whole W every round).  order = np > 0 (nt % np == 0): the complete rounds of an XCD are made
+    // contiguous (its visits r * G + lb become c * R * per + r * per + lb % per), and the sequence walks column groups of np
+    // weight tiles top to bottom — an XCD's 32 concurrent tiles are a (32 / np) x np patch and it stays in one or two
+    // column groups for the whole launch (np x 256 x K weights stay in its L2; an X panel is read by the nt / np XCDs that
+    // walk the same rows at about the same time).  A bijection on [0, n_tiles): the tail tasks use the same map.
+    const int mt = M / 256;
+    auto tile_of = [&](int t, int& tm, int& tn) {
+        if (order <= 0) { tm = t / nt; tn = t - tm * nt; return; }
+        int sq = t;
+        const int R = n_full / G;
+        if (t < R * G && (G & 7) == 0) {
+            const int per = G >> 3, r = t / G, lbv = t - r * G, c = lbv / per;
+            sq = c * (R * per) + r * per + (lbv - c * per);
+        }
+        const int span = mt * order, grp = sq / span, rem = sq - grp * span;
+        tm = rem / order; tn = grp * order + (rem - tm * order);
+    };
     auto pos_of_tile = [&](int t) {
         Pos q;
         q.tile = t; q.kt = 0; q.ok = t < n_full;
-        q.tm = t / nt; q.tn = t - q.tm * nt;
+        tile_of(t, q.tm, q.tn);
         q.xs = (uint32_t)q.tm * 256u * Kb; q.ws = (uint32_t)q.tn * 256u * Kb;
         return q;
     };
@@ -1239,7 +1257,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
     };
     for (int task = lb; task < n_tasks; task += G) {
         const int t = n_full + (task >> 2), mh = (task >> 1) & 1, nh = task & 1;
-        const int ttm = t / nt, ttn = t - ttm * nt;
+        int ttm, ttn;
+        tile_of(t, ttm, ttn);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP_BAR
         const uint32_t txs = (uint32_t)ttm * 256u * Kb + 64u * mh * Kb, tws = (uint32_t)ttn * 256u * Kb + 32u * nh * Kb;

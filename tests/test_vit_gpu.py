@@ -438,14 +438,17 @@ def test_text_tower_errors_are_codes(built, tmp_path):
     assert lib().mi_clip_embed(m._h, out.ctypes.data, 1, out.ctypes.data) == -1                   # image entry point, text handle
 
 
-def test_persistent_gemm_random_shapes_and_grids(built, monkeypatch):
-    """Seeded sweep over (rows, N, K, workgroup count): full rounds, split tails of every size, K depths
-    from 2 to 13 K tiles, with and without the activation — exact on small integers every time."""
+@pytest.mark.parametrize("order", [0, 1, 2, 4])
+def test_persistent_gemm_random_shapes_and_grids(built, monkeypatch, order):
+    """Seeded sweep over (rows, N, K, workgroup count, tile order): full rounds, split tails of every size, K depths
+    from 2 to 13 K tiles, with and without the activation — exact on small integers every time.  order = the
+    column-group tile order of the persistent kernel (0 = row-major; the tower's default is 4, which needs N >= 2048)."""
     rng = np.random.default_rng(2026)
+    monkeypatch.setenv("MI_OP_GEMM_ORDER", str(order))
     for case in range(24):
-        grid = int(rng.choice([1, 2, 3, 5, 8, 13, 32, 256]))
+        grid = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 32, 256]))
         m = int(rng.integers(1, 9)) * 256 - int(rng.integers(0, 200))
-        n = int(rng.choice([256, 512, 768, 1024]))
+        n = int(rng.choice([256, 512, 768, 1024, 2048, 3072] if order == 4 else [256, 512, 768, 1024]))
         k = int(rng.integers(2, 14)) * 64
         monkeypatch.setenv("MI_OP_GRID", str(grid))
         x = rng.integers(-2, 3, (m, k)).astype(np.float32)
@@ -458,16 +461,17 @@ def test_persistent_gemm_random_shapes_and_grids(built, monkeypatch):
 
 
 def test_ab_hooks_of_the_bf16_tower_do_not_change_a_bit(l14):
-    """im2col_rows (the LDS-staged patch gather) and ln_nt (non-temporal write-back of the residual stream) move bytes
-    differently, never compute differently: 40 images (two half-chunk streams), every combination, the same bits."""
+    """im2col_rows (the LDS-staged patch gather), ln_nt (non-temporal write-back of the residual stream) and gemm_order
+    (which tile a workgroup of the persistent GEMM visits when) move bytes differently, never compute differently: 40 images (two half-chunk streams), every combination, the same bits."""
     cfg, w, path, u8, g = l14
     px = synth.preprocess_rgb8(synth.images_u8(78, 40, cfg.image))
     m = Model.from_file(path, 0, PRECISION_BF16)
     ref = m.forward(px)
-    for rows_, nt in ((0, 0), (0, 1), (1, 3)):
+    for rows_, nt, order in ((0, 0, 4), (0, 1, 0), (1, 3, 3), (1, 0, 8)):
         m.set_option("im2col_rows", rows_)
         m.set_option("ln_nt", nt)
-        assert np.array_equal(m.forward(px).view(np.uint32), ref.view(np.uint32)), (rows_, nt)
+        m.set_option("gemm_order", order)   # the persistent GEMM's tile order (0 = row-major, default 4)
+        assert np.array_equal(m.forward(px).view(np.uint32), ref.view(np.uint32)), (rows_, nt, order)
     m.close()
 
 

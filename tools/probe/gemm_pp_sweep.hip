@@ -27,6 +27,7 @@ __global__ void copy16(const v4u* a, v4u* b, size_t n) {
 }
 int main(int argc, char** argv) {
     const int split = argc > 1 ? atoi(argv[1]) : 1;
+    const int order_arg = argc > 2 ? atoi(argv[2]) : 0;   // n-tiles per column group (0 = row-major order)
     struct Shape { int N, K; const char* name; } shapes[] = {{3072, 1024, "qkv"}, {1024, 1024, "out"}, {4096, 1024, "fc1"}, {1024, 4096, "fc2"}};
     const size_t Mmax = 65792;
     bf16_t *X, *W, *O; float* bias; char *junk, *junk2;
@@ -55,8 +56,8 @@ int main(int argc, char** argv) {
                 const int left = n_tiles % grid;
                 const int n_full = (split && left > 0 && left * 4 <= grid) ? n_tiles - left : n_tiles;
                 auto launch = [&] {
-                    if (s.N == 4096) hipLaunchKernelGGL(k2, dim3(grid), dim3(512), 151552, 0, X, W, bias, (void*)O, (int)Mp, s.N, s.K, s.N, n_tiles, n_full, 0);
-                    else hipLaunchKernelGGL(k1, dim3(grid), dim3(512), 151552, 0, X, W, bias, (void*)O, (int)Mp, s.N, s.K, s.N, n_tiles, n_full, 0);
+                    if (s.N == 4096) hipLaunchKernelGGL(k2, dim3(grid), dim3(512), 151552, 0, X, W, bias, (void*)O, (int)Mp, s.N, s.K, s.N, n_tiles, n_full, (order_arg > 0 && (s.N / 256) % order_arg == 0) ? order_arg : 0);
+                    else hipLaunchKernelGGL(k1, dim3(grid), dim3(512), 151552, 0, X, W, bias, (void*)O, (int)Mp, s.N, s.K, s.N, n_tiles, n_full, (order_arg > 0 && (s.N / 256) % order_arg == 0) ? order_arg : 0);
                 };
                 float total = 0, ms = 0; int launches = 0;
                 while (total < 2000.0f) {
@@ -86,8 +87,8 @@ int main(int argc, char** argv) {
             const int left = n_tiles % grid;
             const int n_full = (split && left > 0 && left * 4 <= grid) ? n_tiles - left : n_tiles;
             auto launch = [&] {
-                if (s.N == 4096) hipLaunchKernelGGL(k2, dim3(grid), dim3(512), 151552, 0, X, W, bias, (void*)O, (int)Mp, s.N, s.K, s.N, n_tiles, n_full, 0);
-                else hipLaunchKernelGGL(k1, dim3(grid), dim3(512), 151552, 0, X, W, bias, (void*)O, (int)Mp, s.N, s.K, s.N, n_tiles, n_full, 0);
+                if (s.N == 4096) hipLaunchKernelGGL(k2, dim3(grid), dim3(512), 151552, 0, X, W, bias, (void*)O, (int)Mp, s.N, s.K, s.N, n_tiles, n_full, (order_arg > 0 && (s.N / 256) % order_arg == 0) ? order_arg : 0);
+                else hipLaunchKernelGGL(k1, dim3(grid), dim3(512), 151552, 0, X, W, bias, (void*)O, (int)Mp, s.N, s.K, s.N, n_tiles, n_full, (order_arg > 0 && (s.N / 256) % order_arg == 0) ? order_arg : 0);
             };
             for (int i = 0; i < 3; ++i) launch();
             CK(hipDeviceSynchronize());

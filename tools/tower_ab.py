@@ -14,7 +14,7 @@ import torch
 from image_search_amd import synth
 from image_search_amd.clip import Model, PRECISION_BF16
 
-DEFAULTS = {"sched": 0, "ln_nt": 0, "split_tail": 1, "parts": 2, "part0_short": 0, "grid_cus": 0, "x24": 1}
+DEFAULTS = {"sched": 0, "ln_nt": 0, "split_tail": 1, "parts": 2, "part0_short": 0, "grid_cus": 0, "x24": 1, "gemm_order": 4}
 
 
 def main():
