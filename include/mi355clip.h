@@ -104,6 +104,8 @@ int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* nee
  *   "attn_shift" 1 = always take the shifted (exact row maximum) pass of the bf16 attention (default 0: taken
  *                only for queries whose softmax numerators leave the exponent range; same result)
  *   "split_tail" 0 = do not cut a short last round of GEMM tiles into quadrant tasks (A/B hook)
+ *   "gemm_order" tile order of the persistent GEMM: np > 0 (default 4) = an XCD's concurrent tiles are a (32 / np) x np patch
+ *                inside one column group of np weight tiles (which stay in its L2); 0 = row-major.  Same bits; -2.3 % per forward
  *   "im2col_rows" 0 = the patch gather in 4P-byte runs instead of the LDS-staged rows form (A/B hook; same bits)
  *   "ln_nt"      bit 0 = LN1 writes the residual stream back with non-temporal stores, bit 1 = LN1's last-use loads are
  *                non-temporal (A/B hook, default 0; same bits, no measurable effect)
