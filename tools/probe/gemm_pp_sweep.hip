@@ -22,6 +22,11 @@ __global__ void fill_bf16(bf16_t* p, size_t n, uint64_t seed, float scale) {
         p[i] = f2bf(((int)(z & 0xffff) - 32768) / 32768.0f * scale);
     }
 }
+__global__ void checksum16(const unsigned short* p, size_t n, unsigned long long* out) {   // order-free: sum of (value * (index % 65521 + 1))
+    unsigned long long a = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a += (unsigned long long)p[i] * (i % 65521 + 1);
+    atomicAdd(out, a);
+}
 __global__ void copy16(const v4u* a, v4u* b, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
 }
@@ -92,6 +97,9 @@ int main(int argc, char** argv) {
             };
             for (int i = 0; i < 3; ++i) launch();
             CK(hipDeviceSynchronize());
+            unsigned long long* dsum; unsigned long long hsum = 0; CK(hipMalloc(&dsum, 8)); CK(hipMemset(dsum, 0, 8));
+            hipLaunchKernelGGL(checksum16, 1024, 256, 0, 0, (const unsigned short*)O, Mrows * (size_t)s.N, dsum);
+            CK(hipMemcpy(&hsum, dsum, 8, hipMemcpyDeviceToHost)); CK(hipFree(dsum));
             CK(hipEventRecord(e0));
             for (int i = 0; i < 20; ++i) launch();
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -109,6 +117,7 @@ int main(int argc, char** argv) {
                 }
                 (c ? iso_cold : iso_warm) = acc;
             }
+            printf("[out checksum %016llx] ", hsum);
             printf("M=%zu %s N=%d K=%d tiles=%d (%.3f rounds, tail tasks %d): back-to-back %.1f us = %.0f TF | isolated warm %.1f us = %.0f TF | isolated behind 512 MB of other traffic %.1f us = %.0f TF\n",
                    Mrows, s.name, s.N, s.K, n_tiles, n_tiles / 256.0, (n_tiles - n_full) * 4, rate_us, flop / rate_us / 1e6, iso_warm, flop / iso_warm / 1e6,
                    iso_cold, flop / iso_cold / 1e6);
