@@ -461,6 +461,45 @@ def test_batched_queries_share_one_pass_over_the_byte_mirror(built, k):
     t.close()
 
 
+@pytest.mark.parametrize("k", [3, 64, 1000])
+def test_a_group_with_degenerate_queries_over_a_corpus_with_odd_rows(built, k):
+    """What the single-query tests cover, inside GROUPS: rows with a NaN, an infinity, elements beyond bf16's range, a zero
+    row, tiny and huge multiples of a query, a dominant element, 3 000 exact duplicates (ties by id) in the corpus; a zero
+    query, a NaN query, an infinite query, a stored row and a huge-magnitude query among the group's queries.  Groups of 16,
+    8, 5 and 2, stage 1 on the matrix pipe and on the vector ALU: ids and distance bits of the single pass."""
+    rng = np.random.default_rng(170 + k)
+    t = EmbeddingTable(DIM, 0)
+    t.insert_synthetic(22, 0, N)
+    qs = rng.standard_normal((16, DIM)).astype(np.float32)
+    q = qs[0]
+    odd = rng.standard_normal((7, DIM)).astype(np.float32)
+    odd[0, 5] = np.nan
+    odd[1, 9] = np.inf
+    odd[2] *= np.float32(3.2e38) / np.abs(odd[2]).max()
+    odd[3] = 0.0
+    odd[4] = q * np.float32(1e-17)
+    odd[5] = q * np.float32(1e19)
+    odd[6] = q
+    odd[6, 3] = 1e6
+    t.insert(odd)
+    t.insert(np.repeat(q[None, :] * np.float32(0.5), 3000, 0))
+    qs[1] = 0.0
+    qs[2, 17] = np.nan
+    qs[3, 3] = np.inf
+    qs[4] = t.rows(4321, 1)[0]
+    qs[5] *= np.float32(1e30)                                   # finite, squares overflow fp32
+    qs[6] *= np.float32(1e-30)
+    want = t.knn(qs, k)                                         # prefilter off: the single pass
+    t.set_option("prefilter", 2)
+    for stage1 in (1, 0):
+        t.set_option("batch_stage1", stage1)
+        for lo, nq in ((0, 16), (0, 8), (1, 5), (2, 2), (5, 2)):
+            got = t.knn(qs[lo:lo + nq], k)
+            assert np.array_equal(got[0], want[0][lo:lo + nq]), (stage1, lo, nq)
+            assert np.array_equal(got[1].view(np.uint32), want[1][lo:lo + nq].view(np.uint32)), (stage1, lo, nq)
+    t.close()
+
+
 @pytest.mark.parametrize("k", [10, 1000])
 def test_a_group_in_which_some_queries_fall_back_and_others_do_not(built, k):
     """The queries of a group share every launch, the gated single pass included: query y of the group runs it iff ITS OWN
