@@ -1,3 +1,4 @@
+"""Dev harness (GPU): the attention op hook on a tiny case against numpy, element by element (used while the bf16 kernels were written). Not a test."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,7 @@
+"""Dev harness (GPU): A/B of the two-stage search's sampled threshold (option prefilter_sample = 0 / 1 / 2) at 10 M rows, single queries and groups."""
 import os, sys, json
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from image_search_amd import synth
 from image_search_amd.search import EmbeddingTable
 n = 10_000_000

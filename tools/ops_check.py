@@ -1,3 +1,4 @@
+"""Dev harness (GPU): the op-level hooks (linear, LayerNorm, attention) against numpy on a few shapes. Not a test; tests/test_vit_gpu.py is."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

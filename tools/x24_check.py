@@ -1,9 +1,10 @@
+"""Dev harness (GPU): the 24-bit residual stream (option x24) against the fp32-residual bf16 tower and the transformers golden: error and time.  profiles/r04_x24_residual.json."""
 import os, sys, tempfile, json
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from image_search_amd import synth
 from image_search_amd.clip import Model, PRECISION_BF16
-g = np.load("/root/repo/tests/golden/vit_l14.npz")
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "vit_l14.npz"))
 cfg = synth.VitConfig.vit_l14()
 w = synth.vit_weights(cfg, int(g["seed"]))
 path = os.path.join(tempfile.gettempdir(), f"x24_{os.getpid()}.safetensors")
