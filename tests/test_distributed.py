@@ -36,16 +36,23 @@ def _worker(rank, world, port, n_rows, k, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_search_equals_single_table(tmp_path, orc):
+import pytest
+
+
+@pytest.mark.parametrize("n_rows,k,world", [(5001, 25, 2), (4099, 10, 3), (100, 25, 3)])
+def test_two_rank_sharded_search_equals_single_table(tmp_path, orc, n_rows, k, world):
+    """(5001, 25, 2): the plain case; (4099, 10, 3): an odd number of ranks, uneven shards; (100, 25, 3): shards of 33-34 rows,
+    barely more than k (every shard's list is almost its whole shard)."""
     from image_search_amd import synth
     from oracle.binding import orc_knn
-    n_rows, k, world = 5001, 25, 2
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_rows, k, str(tmp_path)), nprocs=world, join=True)
     rows = synth.corpus_rows(77, 0, n_rows)
     qs = synth.corpus_rows(78, 0, 3)
-    r0 = np.load(tmp_path / "r0.npz"); r1 = np.load(tmp_path / "r1.npz")
-    assert np.array_equal(r0["idx"], r1["idx"]) and np.array_equal(r0["dist"], r1["dist"])
+    r0 = np.load(tmp_path / "r0.npz")
+    for r in range(1, world):
+        r1 = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(r0["idx"], r1["idx"]) and np.array_equal(r0["dist"], r1["dist"])
     for u in range(3):
         fi, fd = orc_knn(orc, qs[u], rows, k)
         assert np.array_equal(r0["idx"][u], fi)
