@@ -113,6 +113,10 @@ SYMBOLS = {
     "mi_op_attention": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_size_t, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int]),
     "mi_op_clock_probe": (ctypes.c_int, [ctypes.c_int, c_vp, ctypes.POINTER(ctypes.c_float)]),
+    "mi_op_linear_lnf": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        ctypes.c_size_t, ctypes.c_int, ctypes.c_int]),
+    "mi_op_linear_resid24": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                            ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_float]),
     "mi_op_layernorm": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t,
                                        ctypes.c_int, ctypes.c_float]),
 }

@@ -14,6 +14,10 @@ struct Layer {
     float *ln1w, *ln1b, *ln2w, *ln2b;
     void *wqkv, *wo, *w1, *w2;  // T [N][K]
     float *bqkv, *bo, *b1, *b2;
+    // the LayerNorm in front of q/k/v and of fc1 folded into the linear (bf16 image tower, option "ln_fold"):
+    // W' = bf16(W diag(gamma)), c[n] = sum_k W'[n][k], b' = W beta + b
+    void *wqkv_f = nullptr, *w1_f = nullptr;
+    float *cqkv = nullptr, *bqkv_f = nullptr, *c1 = nullptr, *b1_f = nullptr;
 };
 
 
@@ -42,14 +46,15 @@ struct mi_clip {
         void *c_ctx = nullptr, *c_y = nullptr, *c_h = nullptr;
         float* c_x = nullptr;
         mi::bf16_t *c_d1 = nullptr, *c_d2 = nullptr;
+        // ln_fold: per-row partial sums written by the out_proj / fc2 epilogues [M][D / 32][2] and what the q/k/v / fc1
+        // epilogues read, {rstd, -mean * rstd} [M][2]
+        float *part = nullptr, *stats = nullptr;
     } act[4];
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    static constexpr int N_EV_SCHED = 256;   // events that tie the R stream and the LayerNorm streams of a scheduled forward (a ring, created on first use)
-    hipEvent_t ev_sched[N_EV_SCHED] = {};
     bool x24 = true;          // bf16 image tower: the residual stream as 24-bit floats in two planes (3 bytes per element instead of 4; option "x24", MI_CLIP_X24)
-    int part0_short = 0;      // two-part forward: the first part takes n/2 - part0_short images (option "part0_short")
-    int sched = 0;            // how a two-part forward is ordered on the chip (forward() in vit.hip; option "sched" / MI_CLIP_SCHED)
+    bool ln_fold = false;     // bf16 image tower without LayerNorm kernels in the layer loop (option "ln_fold", MI_CLIP_LN_FOLD; forward() in vit.hip)
+    bool fold_ready = false;  // the folded weights were built at load (geometry allows it)
     int parts = 2;  // MI_CLIP_PARTS: sub-chunks run as independent streams
     int n_cu = 256;
     uint8_t* d_rgb = nullptr;

@@ -70,6 +70,35 @@ void* upload_mat(mi_clip* m, const std::vector<float>& h, size_t dup_k = 0) {
 
 void load_layers(mi_clip* m, WeightFile& st, const std::string& prefix);
 
+// LayerNorm(gamma, beta) in front of the linear (W [N][K], b): W' = bf16(W diag(gamma)), c[n] = sum_k W'[n][k] (of the
+// ROUNDED weights: the epilogue subtracts mean * c from what the MFMAs accumulated over exactly those), b' = W beta + b.
+// y = W LN(x) + b = rstd * (W' x - mean * c) + b'   (gemm_bf16_pp_kernel<EPI_LNF>)
+void fold_ln(mi_clip* m, const std::vector<float>& w, const std::vector<float>& b, const std::vector<float>& gamma,
+             const std::vector<float>& beta, int N, int K, void** wf, float** c, float** bf) {
+    std::vector<uint16_t> w16((size_t)N * K);
+    std::vector<float> cv(N), bv(N);
+    for (int n = 0; n < N; ++n) {
+        double cs = 0.0, bs = (double)b[n];
+        for (int k = 0; k < K; ++k) {
+            const float v = w[(size_t)n * K + k] * gamma[k];
+            const uint16_t h = f32_to_bf16_host(v);
+            w16[(size_t)n * K + k] = h;
+            uint32_t u = (uint32_t)h << 16;
+            float r;
+            std::memcpy(&r, &u, 4);
+            cs += (double)r;
+            bs += (double)w[(size_t)n * K + k] * (double)beta[k];
+        }
+        cv[n] = (float)cs;
+        bv[n] = (float)bs;
+    }
+    uint16_t* d = dalloc<uint16_t>(m, w16.size(), m->allocs);
+    HIP_CHECK(hipMemcpy(d, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+    *wf = d;
+    *c = upload_f32(m, cv);
+    *bf = upload_f32(m, bv);
+}
+
 // The text tower of the same checkpoint family (HF `CLIPTextModelWithProjection` names): what the
 // reference reaches through embed_anything (server/src/clip.rs:19-23, :35-40).  fp32 only: one
 // query is 77 token rows, latency-bound, and the causal mask exists in the fp32 attention kernel.
@@ -153,6 +182,9 @@ void load_weights(mi_clip* m, const char* path) {
         m->wpatch = upload_mat(m, wp);
     }
     m->q_prescaled = m->precision == MI_PRECISION_BF16 && m->attn_ver == 2 && m->S > 64 && m->S <= 288;
+    // the LayerNorm-free layer loop needs the persistent GEMM on all four linears (256-wide tiles) and a last layer to
+    // hand over to; the folded copies of W_qkv / W_fc1 are built beside the plain ones (option "ln_fold" switches per forward)
+    m->fold_ready = m->precision == MI_PRECISION_BF16 && !m->split_ln && m->D % 256 == 0 && m->FF % 256 == 0 && m->L >= 2;
     load_layers(m, st, v);
 }
 
@@ -184,8 +216,13 @@ void load_layers(mi_clip* m, WeightFile& st, const std::string& v) {
         ly.bqkv = upload_f32(m, bqkv);
         ly.wo = upload_mat(m, st.read(p + "self_attn.out_proj.weight", (int64_t)D * D));
         ly.bo = upload_f32(m, st.read(p + "self_attn.out_proj.bias", D));
-        ly.w1 = upload_mat(m, st.read(p + "mlp.fc1.weight", (int64_t)FF * D), m->split_ln ? (size_t)D : 0);
-        ly.b1 = upload_f32(m, st.read(p + "mlp.fc1.bias", FF));
+        const std::vector<float> w1 = st.read(p + "mlp.fc1.weight", (int64_t)FF * D), b1 = st.read(p + "mlp.fc1.bias", FF);
+        ly.w1 = upload_mat(m, w1, m->split_ln ? (size_t)D : 0);
+        ly.b1 = upload_f32(m, b1);
+        if (m->fold_ready && i + 1 < L) {  // the last layer keeps its LayerNorm kernels (forward())
+            fold_ln(m, wqkv, bqkv, st.read(p + "layer_norm1.weight", D), st.read(p + "layer_norm1.bias", D), 3 * D, D, &ly.wqkv_f, &ly.cqkv, &ly.bqkv_f);
+            fold_ln(m, w1, b1, st.read(p + "layer_norm2.weight", D), st.read(p + "layer_norm2.bias", D), FF, D, &ly.w1_f, &ly.c1, &ly.b1_f);
+        }
         ly.w2 = upload_mat(m, st.read(p + "mlp.fc2.weight", (int64_t)D * FF));
         ly.b2 = upload_f32(m, st.read(p + "mlp.fc2.bias", D));
     }
@@ -218,7 +255,7 @@ void ensure_workspace(mi_clip* m, size_t n) {
     m->d_rgb = (uint8_t*)bytes(n * px);
     const int sets = (m->precision == MI_PRECISION_BF16) ? std::max(1, m->parts) : 1;
     for (int a = 0; a < sets; ++a) {
-        const size_t na = a == 0 ? n : (n + 1) / 2 + (size_t)m->part0_short;  // the second part takes what the first gives up
+        const size_t na = a == 0 ? n : (n + 1) / 2;
         const size_t Ma = pad256(na * m->S), Pa = pad256(na * (m->S - 1));
         if (na == 0) continue;
         m->act[a].col = bytes(Pa * m->Kp * es);
@@ -236,6 +273,10 @@ void ensure_workspace(mi_clip* m, size_t n) {
         m->act[a].c_x = (float*)bytes(Ca * m->D * 4);
         m->act[a].c_d1 = (bf16_t*)bytes(Ca * m->D * 2);
         m->act[a].c_d2 = (bf16_t*)bytes(Ca * m->D * 2);
+        if (m->fold_ready) {
+            m->act[a].part = (float*)bytes(Ma * (size_t)(m->D / 32) * 8);
+            m->act[a].stats = (float*)bytes(Ma * 8);
+        }
     }
     (void)Mp; (void)Pp;
     m->d_out = (float*)bytes(n * m->E * 4);
@@ -275,31 +316,40 @@ void gemm_p(int precision, const void* X, const void* W, const float* bias, void
     HIP_CHECK(hipGetLastError());
 }
 
+// the persistent 256x256 kernel (gemm_bf16_pp_kernel): shapes it takes, and its launch
+bool pp_shape_ok(size_t Mp, int N, int K, int ldo) {
+    return N % 256 == 0 && K % 64 == 0 && K >= 128 && Mp * (size_t)K * 2 < (1ull << 32) && Mp * (size_t)ldo * 2 < (1ull << 32) &&
+           (size_t)N * K * 2 < (1ull << 32);
+}
+template <int EPI>
+void launch_pp(mi_clip* m, const void* X, const void* W, const float* bias, void* out, size_t Mp, int N, int K, int ldo,
+               const PpFold& fold, hipStream_t s) {
+    constexpr bool LNF = EPI == EPI_LNF || EPI == EPI_LNF_QGELU;
+    constexpr int LDS = 131072 + 18432 + 8 * (LNF ? 1536 : 256);
+    auto kern = gemm_bf16_pp_kernel<EPI, bf16_t>;
+    static DevOnce once;
+    allow_lds_once(once, kern, LDS);
+    const int n_tiles = (int)((Mp / 256) * (N / 256));
+    const int grid = std::min(n_tiles * 4, m->n_cu);
+    // a short last round (<= a quarter of the CUs busy) is cut into quadrant tasks
+    const int left = n_tiles % grid;
+    const int n_full = (m->split_tail && left > 0 && left * 4 <= grid) ? n_tiles - left : n_tiles;
+    const int nt = N / 256;
+    auto fits = [&](int np) { return np > 0 && nt > np && nt % np == 0; };
+    const int order = fits(m->gemm_order) ? m->gemm_order : (m->gemm_order > 0 && fits(4)) ? 4 : 0;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, (int)Mp, N, K, ldo,
+                       n_tiles, n_full, order, fold);
+    HIP_CHECK(hipGetLastError());
+}
+
 // bf16 GEMM with bf16 output: the persistent 256x256 kernel when the shape allows, else 128x128
 template <int EPI>
 void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out, size_t Mrows, int N, int K, int ldo,
           hipStream_t s) {
-    const size_t Mp = pad256(Mrows);
-    const bool big = m->precision == MI_PRECISION_BF16 && (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) && N % 256 == 0 &&
-                     K % 64 == 0 && K >= 128 && Mp * (size_t)K * 2 < (1ull << 32) && Mp * (size_t)ldo * 2 < (1ull << 32) &&
-                     (size_t)N * K * 2 < (1ull << 32);
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) {
-        if (big) {
-            constexpr int LDS = 131072 + 18432 + 2048;
-            auto kern = gemm_bf16_pp_kernel<EPI, bf16_t>;
-            static DevOnce once;
-            allow_lds_once(once, kern, LDS);
-            const int n_tiles = (int)((Mp / 256) * (N / 256));
-            const int grid = std::min(n_tiles * 4, m->n_cu);
-            // a short last round (<= a quarter of the CUs busy) is cut into quadrant tasks
-            const int left = n_tiles % grid;
-            const int n_full = (m->split_tail && left > 0 && left * 4 <= grid) ? n_tiles - left : n_tiles;
-            const int nt = N / 256;
-            auto fits = [&](int np) { return np > 0 && nt > np && nt % np == 0; };
-            const int order = fits(m->gemm_order) ? m->gemm_order : (m->gemm_order > 0 && fits(4)) ? 4 : 0;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, (int)Mp, N,
-                               K, ldo, n_tiles, n_full, order);
-            HIP_CHECK(hipGetLastError());
+        const size_t Mp = pad256(Mrows);
+        if (m->precision == MI_PRECISION_BF16 && pp_shape_ok(Mp, N, K, ldo)) {
+            launch_pp<EPI>(m, X, W, bias, out, Mp, N, K, ldo, PpFold(), s);
             return;
         }
     }
@@ -387,66 +437,72 @@ void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, 
     HIP_CHECK(hipGetLastError());
 }
 
+// y pitch / x planes as in layer_norm; x_bias: X24B_BIAS when the planes were written by the LayerNorm-free layers
+void layer_norm_x(mi_clip* m, float* x, const bf16_t* d1, const bf16_t* d2, bool write_back, void* y, const float* w, const float* b,
+                  size_t rows, hipStream_t s, size_t x_lo, uint32_t x_bias) {
+    if (!x_bias) { layer_norm(m, x, d1, d2, write_back, y, w, b, rows, s, x_lo); return; }
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    if (write_back) {
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, true>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, m->D, 0, 0, x_lo, x_bias));
+    } else {
+        MI_LN_DISPATCH(m->D, hipLaunchKernelGGL((ln_kernel<bf16_t, VEC, NT, false>), dim3(blocks), dim3(256), 0, s, x, d1, d2, (bf16_t*)y, w, b, (int)rows, m->eps, m->D, 0, 0, x_lo, x_bias));
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// can this forward run without LayerNorm kernels in the layer loop (option "ln_fold")?
+bool fold_applies(const mi_clip* m, size_t rows_max) {
+    const size_t Mp = pad256(rows_max);
+    return m->ln_fold && m->fold_ready && !m->text && pp_shape_ok(Mp, 3 * m->D, m->D, 3 * m->D) && pp_shape_ok(Mp, m->D, m->D, m->D) &&
+           pp_shape_ok(Mp, m->FF, m->D, m->FF) && pp_shape_ok(Mp, m->D, m->FF, m->D) && Mp * (size_t)(m->D / 32) * 8 < (1ull << 32);
+}
+
 // the whole tower on n <= cap device-resident images.
 // bf16, n >= 32: the chunk is cut into two halves that run as two independent streams with their
 // own activation sets, launches interleaved layer by layer.  The persistent GEMM of one half
-// owns every CU's LDS while it runs, but the other half's LayerNorms (no LDS, 60 VGPRs) share
+// owns every CU's LDS while it runs, but the other half's small kernels share
 // the CUs with it, and whichever kernel of the other half is next fills the CUs that fall idle
 // in a GEMM's last, partial round of tiles (257 row-tiles never divide by 256 CUs).
+//
+// Two forms of the bf16 layer loop:
+//  * LayerNorm kernels (default): out_proj / fc2 store bf16 `delta` / `delta2` (pure, asynchronous stores from the
+//    persistent GEMM).  LN2 normalises x + delta without writing x; the next LN1 forms (x + delta) + delta2 — the same
+//    order — writes it back and normalises it.
+//  * LayerNorm-free (option "ln_fold", layers 0 .. L-2): the residual stream lives as two planes whose hi plane is bf16(x).
+//    q/k/v and fc1 read that plane as it lies, with gamma folded into their weights, and finish the LayerNorm in their
+//    epilogue from per-row {rstd, -mean rstd} (EPI_LNF); out_proj / fc2 add their output to the planes in place and emit
+//    per-row partial sums (EPI_RESID24), which ln_stats_kernel turns into the next {rstd, -mean rstd}.  The last layer
+//    runs on LayerNorm kernels again (it works on the CLS rows only).
+// fp32 path: the residual add is the GEMM epilogue (x += acc + bias, fp32 read-modify-write).
 void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t s0) {
     const int D = m->D, S = m->S, FF = m->FF;
     const size_t px = (size_t)m->image * m->image * 3;
     const bool deferred = m->precision == MI_PRECISION_BF16;
     const int Kln = m->split_ln ? 2 * D : D;  // K of the GEMMs fed by a LayerNorm (q/k/v, fc1): hi | lo halves when split
     const int parts = (deferred && m->parts > 1 && n >= 32) ? m->parts : 1;
-    // Scheduling of a two-part forward (option "sched").  The persistent GEMMs and attention need a whole CU's LDS: they
-    // exclude one another ("R" work); the LayerNorms need none and run beside them ("L" work).
-    //   0: every part on its own stream, nothing between them (the hardware queues arbitrate).
-    //   1: all R work of both parts on ONE stream in the order A.R1 B.R1 A.R2 B.R2 (R1 = qkv, attention, out_proj;
-    //      R2 = fc1, fc2), each part's LayerNorms on a stream of its own, tied to the R stream by events: a part's
-    //      LayerNorm always runs beside the other part's R block, and two GEMMs never share the chip.
-    //   2: every part on its own stream as in 0, R blocks chained across the streams by events in the same order.
-    const int sched = parts == 2 ? m->sched : 0;
-    struct Part { size_t n, M, P; const float* img; float* out; hipStream_t rs, ls; mi_clip::Act* a; const bf16_t *p1, *p2; size_t xlo; } pt[4];
+    struct Part { size_t n, M, P; const float* img; float* out; hipStream_t s; mi_clip::Act* a; const bf16_t *p1, *p2; size_t xlo; } pt[4];
+    const bool fold = deferred && fold_applies(m, (n / parts + 1) * (size_t)S);
     // the residual stream as 24-bit floats in two planes (option "x24"; bf16 tower, D a multiple of 256, no hi + lo LayerNorm outputs)
-    const bool x24 = deferred && m->x24 && !m->split_ln && D % 256 == 0;
-    auto aux = [&](int i) {
-        if (!m->aux[i]) HIP_CHECK(hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking));
-        return m->aux[i];
-    };
+    const bool x24 = fold || (deferred && m->x24 && !m->split_ln && D % 256 == 0);
+    const uint32_t x_bias = fold ? X24B_BIAS : 0u;
     for (size_t p = 0, first = 0; p < (size_t)parts; ++p) {
-        size_t np = n / parts + (p < n % parts ? 1 : 0);
-        // two parts: the first may be given fewer images so that its token rows fill whole rounds of 256-row tiles
-        // (127 images = 32 639 rows = 128 row tiles = exactly 2 / 6 / 8 rounds of the four GEMMs on 256 CUs)
-        if (parts == 2 && m->part0_short > 0 && n > 2 * (size_t)m->part0_short) np = p == 0 ? n / 2 - m->part0_short : n - (n / 2 - m->part0_short);
-        hipStream_t rs = p == 0 ? s0 : nullptr, ls = nullptr;
-        if (sched == 1) { rs = s0; ls = aux(0); }  // ONE LayerNorm stream: in the intended order they never overlap one another
-        else { if (p > 0) rs = aux((int)p - 1); ls = rs; }
-        pt[p] = {np, np * S, np * (S - 1), d_img + first * px, d_out + first * m->E, rs, ls, &m->act[p], nullptr, nullptr,
+        const size_t np = n / parts + (p < n % parts ? 1 : 0);
+        hipStream_t st = s0;
+        if (p > 0) {
+            if (!m->aux[p - 1]) HIP_CHECK(hipStreamCreateWithFlags(&m->aux[p - 1], hipStreamNonBlocking));
+            st = m->aux[p - 1];
+        }
+        pt[p] = {np, np * S, np * (S - 1), d_img + first * px, d_out + first * m->E, st, &m->act[p], nullptr, nullptr,
                  x24 ? pad256(np * S) * (size_t)D * 2 : (size_t)0};   // the lo plane lies behind a hi plane of the part's padded rows
         first += np;
     }
-    // Events are recorded the moment their producer is enqueued (an event recorded later would also cover whatever the
-    // stream was given in between — e.g. the other part's LayerNorm — and tie the consumer to that too).
-    int ev_next = 0;
-    auto post = [&](hipStream_t from) {
-        hipEvent_t& e = m->ev_sched[ev_next++ % mi_clip::N_EV_SCHED];
-        if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIP_CHECK(hipEventRecord(e, from));
-        return e;
-    };
-    auto await = [&](hipStream_t to, hipEvent_t e) { if (e) HIP_CHECK(hipStreamWaitEvent(to, e, 0)); };
-    hipEvent_t ev_ln[4] = {}, ev_r[4] = {}, ev_rprev = nullptr;  // per part: its last LayerNorm / R block; sched 2: the last R block of any part
     if (parts > 1) {
         HIP_CHECK(hipEventRecord(m->ev_fork, s0));
-        for (int p = 0; p < parts; ++p) {
-            if (pt[p].ls != s0) HIP_CHECK(hipStreamWaitEvent(pt[p].ls, m->ev_fork, 0));
-            if (pt[p].rs != s0 && pt[p].rs != pt[p].ls) HIP_CHECK(hipStreamWaitEvent(pt[p].rs, m->ev_fork, 0));
-        }
+        for (int p = 1; p < parts; ++p) HIP_CHECK(hipStreamWaitEvent(pt[p].s, m->ev_fork, 0));
     }
     for (int p = 0; p < parts; ++p) {
         Part& q = pt[p];
-        hipStream_t fs = q.ls;  // the front of a part runs on its L stream
+        hipStream_t fs = q.s;
         // patch embedding: gather -> GEMM [P,Kp] x [D,Kp]^T -> f32
         const size_t total = q.P * 3 * (size_t)m->patch;  // one thread per patch-row segment
         const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65535 * 4);
@@ -459,51 +515,57 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
             hipLaunchKernelGGL((im2col_kernel<bf16_t>), dim3(blocks), dim3(256), 0, fs, q.img, (bf16_t*)q.a->col, (int)q.n, m->grid, m->patch, m->image, m->Kp);
         HIP_CHECK(hipGetLastError());
         gemm<EPI_STORE_F32>(m, q.a->col, m->wpatch, nullptr, q.a->patch, q.P, D, m->Kp, D, fs);
-        const unsigned lb = (unsigned)((q.M + 3) / 4);
-        MI_LN_DISPATCH(D, hipLaunchKernelGGL((embed_ln_kernel<VEC, NT>), dim3(lb), dim3(256), 0, fs, q.a->patch, m->cls, m->pos, q.a->x, m->pre_w, m->pre_b, (int)q.M, S, m->eps, q.xlo));
+        const size_t rows_launch = fold ? pad256(q.M) : q.M;   // ln_fold: the padding rows get a defined (zero) residual too
+        const unsigned lb = (unsigned)((rows_launch + 3) / 4);
+        MI_LN_DISPATCH(D, hipLaunchKernelGGL((embed_ln_kernel<VEC, NT>), dim3(lb), dim3(256), 0, fs, q.a->patch, m->cls, m->pos, q.a->x, m->pre_w, m->pre_b, (int)q.M, S, m->eps, q.xlo,
+                                             fold ? q.a->stats : (float*)nullptr, (int)rows_launch));
         HIP_CHECK(hipGetLastError());
     }
-    // fp32 path: the residual add is the GEMM epilogue (x += acc + bias, fp32 read-modify-write).
-    // bf16 path: out_proj / fc2 store bf16 `delta` / `delta2` (pure, asynchronous stores from the
-    // persistent GEMM).  LN2 normalises x + delta without writing x; the next LN1 forms
-    // (x + delta) + delta2 — the same order — writes it back and normalises it.
     // The pooled output is the CLS row (modeling_clip.py:641-651), so behind the LAST layer's attention
     // only that row of every image is live: its context row is gathered and out_proj, LN2, the MLP and
     // the head run on n rows instead of n*S (same arithmetic per row, so the same bits; the reference's
     // graph computes the other rows and discards them).  Option "full_last" keeps the full last layer.
     const bool full_last = m->full_last;
-    hipStream_t r_prev = nullptr;  // sched 2: the stream of the R block enqueued last
-    auto r_enter = [&](int p) {    // in front of an R block of part p
-        Part& q = pt[p];
-        if (q.ls != q.rs) await(q.rs, ev_ln[p]);                       // its LayerNorm output (sched 1)
-        if (sched == 2 && r_prev && r_prev != q.rs) await(q.rs, ev_rprev);
+    const int nb = D / 32;
+    auto ln_stats = [&](Part& q) {   // the partial sums of the GEMM just enqueued -> {rstd, -mean rstd} per (padded) row
+        const size_t Mp = pad256(q.M);
+        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(Mp / 256)), dim3(256), 0, q.s, q.a->part, q.a->stats, (int)Mp, nb, 1.0f / (float)D, m->eps);
+        HIP_CHECK(hipGetLastError());
     };
-    auto r_leave = [&](int p) {
-        Part& q = pt[p];
-        if (q.ls != q.rs) ev_r[p] = post(q.rs);
-        if (sched == 2) { ev_rprev = post(q.rs); r_prev = q.rs; }
-    };
-    auto ln_enter = [&](int p) { if (pt[p].ls != pt[p].rs) await(pt[p].ls, ev_r[p]); };
-    auto ln_leave = [&](int p) { if (pt[p].ls != pt[p].rs) ev_ln[p] = post(pt[p].ls); };
     for (size_t li = 0; li < m->layers.size(); ++li) {
         const Layer& ly = m->layers[li];
         const bool last = !full_last && li + 1 == m->layers.size();
-        // ---- LN1 (L), then R1 = qkv, attention[, out_proj]
+        const bool lnf = fold && li + 1 < m->layers.size();   // this layer runs without LayerNorm kernels
+        // ---- LN1, q/k/v, attention of every part; then the rest of every part
         for (int p = 0; p < parts; ++p) {
             Part& q = pt[p];
-            ln_enter(p);
-            layer_norm(m, q.a->x, q.p1, q.p2, true, q.a->y, ly.ln1w, ly.ln1b, q.M, q.ls, q.xlo);
-            ln_leave(p);
-            if (sched == 0) {  // as launched since round 1: LN1, qkv, attention of every part, then the rest of every part
-                if (!last) gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, Kln, 3 * D, q.rs);
+            if (lnf) {
+                PpFold f;
+                f.cvec = ly.cqkv; f.stats = q.a->stats;
+                launch_pp<EPI_LNF>(m, q.a->x, ly.wqkv_f, ly.bqkv_f, q.a->qkv, pad256(q.M), 3 * D, D, 3 * D, f, q.s);
+                attention(m, q.a->qkv, q.a->y, q.n, q.s, false);
+                continue;
             }
-            if (sched != 0 || last) continue;
-            attention(m, q.a->qkv, q.a->y, q.n, q.rs, false);
+            layer_norm_x(m, q.a->x, q.p1, q.p2, true, q.a->y, ly.ln1w, ly.ln1b, q.M, q.s, q.xlo, x_bias);
+            if (last) continue;
+            gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, Kln, 3 * D, q.s);
+            attention(m, q.a->qkv, q.a->y, q.n, q.s, false);
         }
         for (int p = 0; p < parts; ++p) {
             Part& q = pt[p];
-            if (sched != 0) r_enter(p);
-            hipStream_t s = q.rs;
+            hipStream_t s = q.s;
+            if (lnf) {
+                PpFold f;
+                f.xlo = (uint8_t*)q.a->x + q.xlo; f.part = q.a->part;
+                launch_pp<EPI_RESID24>(m, q.a->y, ly.wo, ly.bo, q.a->x, pad256(q.M), D, D, D, f, s);
+                ln_stats(q);
+                PpFold f1;
+                f1.cvec = ly.c1; f1.stats = q.a->stats;
+                launch_pp<EPI_LNF_QGELU>(m, q.a->x, ly.w1_f, ly.b1_f, q.a->h, pad256(q.M), FF, D, FF, f1, s);
+                launch_pp<EPI_RESID24>(m, q.a->h, ly.w2, ly.b2, q.a->x, pad256(q.M), D, FF, D, f, s);
+                if (li + 2 < m->layers.size()) ln_stats(q);   // the last layer's LayerNorm kernel reads the planes themselves
+                continue;
+            }
             if (last) {
                 // keys and values of every token, queries of the CLS rows only (the other rows of the
                 // leading query tile keep whatever the buffer held: their context rows are never read)
@@ -517,11 +579,10 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
                 else hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3(gb), dim3(256), 0, s, (const float*)q.a->c_ctx, (float*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)3 * D);
                 HIP_CHECK(hipGetLastError());
                 attention(m, q.a->qkv, q.a->y, q.n, s, true);
-                // the rest of the last layer is a few hundred rows: it stays on the R stream, LayerNorm included
                 const unsigned gb2 = gb;
                 if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb2), dim3(256), 0, s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_ctx, (int)q.n, (size_t)S, D);
                 else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb2), dim3(256), 0, s, (const float*)q.a->y, (float*)q.a->c_ctx, (int)q.n, (size_t)S, D);
-                if (q.xlo) hipLaunchKernelGGL(gather_rows_x24_kernel, dim3(gb2), dim3(256), 0, s, (const uint16_t*)q.a->x, (const uint8_t*)q.a->x + q.xlo, q.a->c_x, (int)q.n, (size_t)S, D);
+                if (q.xlo) hipLaunchKernelGGL(gather_rows_x24_kernel, dim3(gb2), dim3(256), 0, s, (const uint16_t*)q.a->x, (const uint8_t*)q.a->x + q.xlo, q.a->c_x, (int)q.n, (size_t)S, D, x_bias);
                 else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb2), dim3(256), 0, s, (const float*)q.a->x, q.a->c_x, (int)q.n, (size_t)S, D);
                 HIP_CHECK(hipGetLastError());
                 if (deferred) {
@@ -537,58 +598,27 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
                 }
                 MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, s, q.a->c_x, deferred ? q.a->c_d1 : (const bf16_t*)nullptr, deferred ? q.a->c_d2 : (const bf16_t*)nullptr, m->post_w, m->post_b, m->proj, q.out, (int)q.n, 1, m->E, m->eps, (const int*)nullptr));
                 HIP_CHECK(hipGetLastError());
-                r_leave(p);
                 continue;
-            }
-            if (sched != 0) {
-                gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, Kln, 3 * D, s);
-                attention(m, q.a->qkv, q.a->y, q.n, s, false);
             }
             if (deferred) gemm<EPI_BIAS>(m, q.a->y, ly.wo, ly.bo, q.a->delta, q.M, D, D, D, s);
             else gemm<EPI_BIAS_RESID>(m, q.a->y, ly.wo, ly.bo, q.a->x, q.M, D, D, D, s);
-            if (sched != 0) r_leave(p);
-            // ---- LN2 (L)
-            ln_enter(p);
-            if (deferred) layer_norm(m, q.a->x, q.a->delta, nullptr, false, q.a->y, ly.ln2w, ly.ln2b, q.M, q.ls, q.xlo);
-            else layer_norm(m, q.a->x, nullptr, nullptr, true, q.a->y, ly.ln2w, ly.ln2b, q.M, q.ls);
-            ln_leave(p);
-            if (sched == 0) {  // R2 right behind, on the part's own stream
-                gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, Kln, FF, s);
-                if (deferred) { gemm<EPI_BIAS>(m, q.a->h, ly.w2, ly.b2, q.a->delta2, q.M, D, FF, D, s); q.p1 = q.a->delta; q.p2 = q.a->delta2; }
-                else gemm<EPI_BIAS_RESID>(m, q.a->h, ly.w2, ly.b2, q.a->x, q.M, D, FF, D, s);
-            }
-        }
-        if (last) break;
-        // ---- R2 = fc1, fc2
-        for (int p = 0; p < parts && sched != 0; ++p) {
-            Part& q = pt[p];
-            r_enter(p);
-            hipStream_t s = q.rs;
+            if (deferred) layer_norm_x(m, q.a->x, q.a->delta, nullptr, false, q.a->y, ly.ln2w, ly.ln2b, q.M, s, q.xlo, x_bias);
+            else layer_norm(m, q.a->x, nullptr, nullptr, true, q.a->y, ly.ln2w, ly.ln2b, q.M, s);
             gemm<EPI_BIAS_QGELU>(m, q.a->y, ly.w1, ly.b1, q.a->h, q.M, FF, Kln, FF, s);
             if (deferred) { gemm<EPI_BIAS>(m, q.a->h, ly.w2, ly.b2, q.a->delta2, q.M, D, FF, D, s); q.p1 = q.a->delta; q.p2 = q.a->delta2; }
             else gemm<EPI_BIAS_RESID>(m, q.a->h, ly.w2, ly.b2, q.a->x, q.M, D, FF, D, s);
-            r_leave(p);
         }
+        if (last) break;
     }
     for (int p = 0; p < parts && full_last; ++p) {
         Part& q = pt[p];
-        ln_enter(p);
         // fp32 in both precisions: the embedding that goes to the table is not rounded to bf16 anywhere here
-        MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, q.ls, q.a->x, q.p1, q.p2, m->post_w, m->post_b, m->proj, q.out, (int)q.n, S, m->E, m->eps, (const int*)nullptr, q.xlo));
+        MI_LN_DISPATCH(D, hipLaunchKernelGGL((head_kernel<VEC, NT>), dim3((unsigned)((q.n + 7) / 8), 16), dim3(256), 0, q.s, q.a->x, q.p1, q.p2, m->post_w, m->post_b, m->proj, q.out, (int)q.n, S, m->E, m->eps, (const int*)nullptr, q.xlo, x_bias));
         HIP_CHECK(hipGetLastError());
     }
-    if (parts > 1) {
-        hipStream_t seen[8]; int ns = 0, j = 0;
-        for (int p = 0; p < parts; ++p)
-            for (hipStream_t st : {pt[p].rs, pt[p].ls}) {
-                bool dup = st == s0;
-                for (int i = 0; i < ns; ++i) dup = dup || seen[i] == st;
-                if (dup) continue;
-                seen[ns++] = st;
-                HIP_CHECK(hipEventRecord(m->ev_join[j], st));
-                HIP_CHECK(hipStreamWaitEvent(s0, m->ev_join[j], 0));
-                ++j;
-            }
+    for (int p = 1; p < parts; ++p) {
+        HIP_CHECK(hipEventRecord(m->ev_join[p - 1], pt[p].s));
+        HIP_CHECK(hipStreamWaitEvent(s0, m->ev_join[p - 1], 0));
     }
 }
 
@@ -761,7 +791,6 @@ void free_model(mi_clip* m) {
     for (auto& a : m->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
     m->order.destroy();
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    for (auto& e : m->ev_sched) if (e) (void)hipEventDestroy(e);
     for (auto& e : m->ev_join) if (e) (void)hipEventDestroy(e);
     if (m->copy_stream) { (void)hipStreamSynchronize(m->copy_stream); (void)hipStreamDestroy(m->copy_stream); }
     for (int b = 0; b < 2; ++b) {
@@ -829,23 +858,10 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         else if (k == "text_fast") m->text_fast = value != 0;
         else if (k == "ln_nt") m->ln_nt = value & 3;
         else if (k == "x24") m->x24 = value != 0;   // takes effect with the next forward (every forward rewrites the residual stream)
-        else if (k == "grid_cus") {  // A/B hook: cap of the persistent kernels' grids (GEMM, attention); 0 = every CU
-            if (value < 0 || value > 4096) fail(MI_ERR_INVALID, "grid_cus out of range");
-            hipDeviceProp_t prop;
-            HIP_CHECK(hipGetDeviceProperties(&prop, m->device));
-            m->n_cu = value > 0 ? std::min(value, prop.multiProcessorCount) : prop.multiProcessorCount;
-        } else if (k == "part0_short") {
-            if (value < 0 || value > 64) fail(MI_ERR_INVALID, "part0_short must be 0..64");
-            if (value != m->part0_short) {  // the second activation set grows: rebuild on next use
-                m->order.sync();
-                for (void* p : m->ws) HIP_CHECK(hipFree(p));
-                m->ws.clear();
-                m->cap = 0;
-                m->part0_short = value;
-            }
-        } else if (k == "sched") {
-            if (value < 0 || value > 2) fail(MI_ERR_INVALID, "sched must be 0, 1 or 2");
-            m->sched = value;
+        else if (k == "ln_fold") {   // takes effect with the next forward (every forward rewrites the residual stream)
+            if (value != 0 && !m->fold_ready)
+                fail(MI_ERR_UNSUPPORTED, "ln_fold needs the bf16 image tower with hidden and intermediate sizes that are multiples of 256 and at least two layers");
+            m->ln_fold = value != 0;
         }
         else if (k == "max_batch") {
             if (value < 1) fail(MI_ERR_INVALID, "max_batch must be >= 1");
@@ -860,7 +876,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, gemm_order, im2col_rows, ln_nt, sched, x24, part0_short, grid_cus, text_fast, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, max_batch, parts)", key);
     });
 }
 
@@ -890,11 +906,11 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         if (const char* e = std::getenv("MI_CLIP_IM2COL")) m->im2col_rows = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_CLIP_LN_NT")) m->ln_nt = std::atoi(e) & 3;
         if (const char* e = std::getenv("MI_CLIP_X24")) m->x24 = std::atoi(e) != 0;
-        if (const char* e = std::getenv("MI_CLIP_SCHED")) m->sched = std::min(2, std::max(0, std::atoi(e)));
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         m->n_cu = prop.multiProcessorCount;
         load_weights(m, weights_path);
+        if (const char* e = std::getenv("MI_CLIP_LN_FOLD")) m->ln_fold = std::atoi(e) != 0 && m->fold_ready;
         *out = m;
     });
     if (rc != MI_OK && m) free_model(m);
@@ -1183,6 +1199,94 @@ int mi_op_linear(int device, int precision, int epilogue, const float* x, const 
         }
         HIP_CHECK(hipDeviceSynchronize());
         sc.down(f32_out ? MI_PRECISION_F32 : precision, dout, out, m_rows * n);
+    });
+}
+
+// the two epilogues of the LayerNorm-free tower, one persistent-GEMM launch each (bf16; MI_OP_GRID / MI_OP_GEMM_ORDER as in mi_op_linear)
+namespace {
+void op_pp_model(mi_clip& mm, int device) {
+    mm.precision = MI_PRECISION_BF16;
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    mm.n_cu = prop.multiProcessorCount;
+    if (const char* e = std::getenv("MI_OP_GRID")) mm.n_cu = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("MI_OP_GEMM_ORDER")) mm.gemm_order = std::max(0, std::min(16, std::atoi(e)));
+    if (const char* e = std::getenv("MI_GEMM_SPLIT")) mm.split_tail = std::atoi(e) != 0;
+}
+}  // namespace
+
+int mi_op_linear_lnf(int device, int epilogue, const float* x, const float* w, const float* bias, const float* c,
+                     const float* stats, float* out, size_t m_rows, int n, int k) {
+    return guarded([&] {
+        if (!x || !w || !bias || !c || !stats || !out) fail(MI_ERR_INVALID, "null buffer");
+        if (epilogue != EPI_LNF && epilogue != EPI_LNF_QGELU) fail(MI_ERR_INVALID, "epilogue %d", epilogue);
+        const size_t mp = pad256(m_rows);
+        if (!pp_shape_ok(mp, n, k, n)) fail(MI_ERR_UNSUPPORTED, "shape [%zu x %d x %d] is not one of the persistent GEMM's", m_rows, n, k);
+        DeviceGuard g(device);
+        Scratch sc;
+        void* dx = sc.up(MI_PRECISION_BF16, x, m_rows, k, mp);
+        void* dw = sc.up(MI_PRECISION_BF16, w, n, k, n);
+        float* db = (float*)sc.up(MI_PRECISION_F32, bias, 1, n, 1);
+        PpFold f;
+        f.cvec = (float*)sc.up(MI_PRECISION_F32, c, 1, n, 1);
+        f.stats = (float*)sc.up(MI_PRECISION_F32, stats, m_rows, 2, mp);
+        void* dout = sc.bytes(mp * n * 2);
+        mi_clip mm;
+        op_pp_model(mm, device);
+        if (epilogue == EPI_LNF) launch_pp<EPI_LNF>(&mm, dx, dw, db, dout, mp, n, k, n, f, nullptr);
+        else launch_pp<EPI_LNF_QGELU>(&mm, dx, dw, db, dout, mp, n, k, n, f, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        sc.down(MI_PRECISION_BF16, dout, out, m_rows * n);
+    });
+}
+
+int mi_op_linear_resid24(int device, const float* x, const float* w, const float* bias, float* xres, float* hi_out,
+                         float* part, float* stats, size_t m_rows, int n, int k, float eps) {
+    return guarded([&] {
+        if (!x || !w || !bias || !xres) fail(MI_ERR_INVALID, "null buffer");
+        const size_t mp = pad256(m_rows);
+        if (!pp_shape_ok(mp, n, k, n) || mp * (size_t)(n / 32) * 8 >= (1ull << 32))
+            fail(MI_ERR_UNSUPPORTED, "shape [%zu x %d x %d] is not one of the persistent GEMM's", m_rows, n, k);
+        DeviceGuard g(device);
+        Scratch sc;
+        void* dx = sc.up(MI_PRECISION_BF16, x, m_rows, k, mp);
+        void* dw = sc.up(MI_PRECISION_BF16, w, n, k, n);
+        float* db = (float*)sc.up(MI_PRECISION_F32, bias, 1, n, 1);
+        // the residual rows as the two planes: b' = bits + 0x8080, hi = b' >> 16, lo = (b' >> 8) & 0xFF; padding rows = 0.0
+        const size_t cnt = mp * (size_t)n;
+        std::vector<uint16_t> hi(cnt, 0);
+        std::vector<uint8_t> lo(cnt, 0x80);
+        for (size_t i = 0; i < m_rows * (size_t)n; ++i) {
+            uint32_t u;
+            std::memcpy(&u, &xres[i], 4);
+            u += 0x8080u;
+            hi[i] = (uint16_t)(u >> 16);
+            lo[i] = (uint8_t)(u >> 8);
+        }
+        uint16_t* dhi = (uint16_t*)sc.bytes(cnt * 2);
+        uint8_t* dlo = (uint8_t*)sc.bytes(cnt);
+        HIP_CHECK(hipMemcpy(dhi, hi.data(), cnt * 2, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dlo, lo.data(), cnt, hipMemcpyHostToDevice));
+        const int nb = n / 32;
+        PpFold f;
+        f.xlo = dlo;
+        f.part = (float*)sc.bytes(mp * nb * 8);
+        float* dstats = (float*)sc.bytes(mp * 8);
+        mi_clip mm;
+        op_pp_model(mm, device);
+        launch_pp<EPI_RESID24>(&mm, dx, dw, db, dhi, mp, n, k, n, f, nullptr);
+        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(mp / 256)), dim3(256), 0, nullptr, f.part, dstats, (int)mp, nb, 1.0f / (float)n, eps);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(hi.data(), dhi, cnt * 2, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(lo.data(), dlo, cnt, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < m_rows * (size_t)n; ++i) {
+            const uint32_t u = (((uint32_t)hi[i] << 16) | ((uint32_t)lo[i] << 8)) - X24B_BIAS;
+            std::memcpy(&xres[i], &u, 4);
+            if (hi_out) { const uint32_t h = (uint32_t)hi[i] << 16; std::memcpy(&hi_out[i], &h, 4); }
+        }
+        if (part) HIP_CHECK(hipMemcpy(part, f.part, m_rows * nb * 8, hipMemcpyDeviceToHost));
+        if (stats) HIP_CHECK(hipMemcpy(stats, dstats, m_rows * 8, hipMemcpyDeviceToHost));
     });
 }
 

@@ -36,7 +36,19 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
-enum { EPI_STORE_F32 = 0, EPI_BIAS = 1, EPI_BIAS_QGELU = 2, EPI_BIAS_RESID = 3 };
+enum { EPI_STORE_F32 = 0, EPI_BIAS = 1, EPI_BIAS_QGELU = 2, EPI_BIAS_RESID = 3,
+       // the tower WITHOUT LayerNorm kernels (option "ln_fold", persistent bf16 GEMM only):
+       EPI_LNF = 4,        // out = rstd[m] * acc + (-mean[m] * rstd[m]) * c[n] + b'[n]: the LayerNorm in front of this linear, folded
+       EPI_LNF_QGELU = 5,  // ... followed by QuickGELU (fc1)
+       EPI_RESID24 = 6 };  // x[m][n] += bf16(acc + bias) on the 24-bit residual planes in place, + per-row partial sums of x and x^2
+
+// extra operands of the EPI_LNF* / EPI_RESID24 epilogues of gemm_bf16_pp_kernel
+struct PpFold {
+    const float* cvec = nullptr;   // EPI_LNF*: c[n] = sum_k float(W'[n][k]), W' = bf16(W * diag(gamma))
+    const float* stats = nullptr;  // EPI_LNF*: [M][2] = {rstd, -mean * rstd} of the rows of X (ln_stats_kernel / embed_ln_kernel)
+    uint8_t* xlo = nullptr;        // EPI_RESID24: lo plane [M][ldo] of the residual stream (its hi plane is `out`)
+    float* part = nullptr;         // EPI_RESID24: [M][N / 32][2] = {sum, sum of squares} of the new x over each 32-column block
+};
 
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
@@ -191,25 +203,32 @@ struct LnRow {
     // pattern (sign, exponent, 7 mantissa bits), lo = the next 8 mantissa bits — 16 significant bits, 3 bytes per element
     // instead of 4.  The LayerNorms are pure HBM traffic and cost the forward their full stand-alone time:
     // the fp32 residual is 12 of their 22 bytes per element and layer, this makes it 9.  Rounded to nearest when stored.
-    __device__ __forceinline__ void load_x24(const uint16_t* __restrict__ hi, const uint8_t* __restrict__ lo, int lane) {
+    // bias: 0 for the truncated planes written by store_x24; X24B_BIAS for the planes of the LayerNorm-free tower, whose hi
+    // plane is bf16(x) rounded to nearest (resid24_step, store_x24 with round = 0x8080)
+    __device__ __forceinline__ void load_x24(const uint16_t* __restrict__ hi, const uint8_t* __restrict__ lo, int lane, uint32_t bias = 0) {
         static_assert(VEC == 4, "four elements per lane and chunk");
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const v2u h = *reinterpret_cast<const v2u*>(hi + (t * 64 + lane) * 4);
             const uint32_t l = *reinterpret_cast<const uint32_t*>(lo + (t * 64 + lane) * 4);
-            v[t * 4 + 0] = __uint_as_float((h.x << 16) | ((l & 0xFFu) << 8));
-            v[t * 4 + 1] = __uint_as_float((h.x & 0xFFFF0000u) | (l & 0xFF00u));
-            v[t * 4 + 2] = __uint_as_float((h.y << 16) | ((l >> 8) & 0xFF00u));
-            v[t * 4 + 3] = __uint_as_float((h.y & 0xFFFF0000u) | ((l >> 16) & 0xFF00u));
+            v[t * 4 + 0] = __uint_as_float(((h.x << 16) | ((l & 0xFFu) << 8)) - bias);
+            v[t * 4 + 1] = __uint_as_float(((h.x & 0xFFFF0000u) | (l & 0xFF00u)) - bias);
+            v[t * 4 + 2] = __uint_as_float(((h.y << 16) | ((l >> 8) & 0xFF00u)) - bias);
+            v[t * 4 + 3] = __uint_as_float(((h.y & 0xFFFF0000u) | ((l >> 16) & 0xFF00u)) - bias);
         }
     }
-    __device__ __forceinline__ void store_x24(uint16_t* __restrict__ hi, uint8_t* __restrict__ lo, int lane) const {
+    // round: 0x80 = to 24 bits, nearest (ties up); 0x8080 = the same plus half a bf16 ulp (load_x24 with bias X24B_BIAS).
+    // Inf and NaN patterns are stored as they are (an increment could carry a NaN's payload into the sign bit).
+    __device__ __forceinline__ void store_x24(uint16_t* __restrict__ hi, uint8_t* __restrict__ lo, int lane, uint32_t round = 0x80u) const {
         static_assert(VEC == 4, "four elements per lane and chunk");
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             uint32_t r[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) r[c] = __float_as_uint(v[t * 4 + c]) + 0x80u;   // round to 24 bits, nearest (ties up)
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t u = __float_as_uint(v[t * 4 + c]);
+                r[c] = (u & 0x7F800000u) == 0x7F800000u ? u + (round & 0x8000u) : u + round;
+            }
             v2u h;
             h.x = (r[0] >> 16) | (r[1] & 0xFFFF0000u);
             h.y = (r[2] >> 16) | (r[3] & 0xFFFF0000u);
@@ -318,7 +337,7 @@ template <typename T, int VEC, int NT, bool WRITE_BACK>
 __device__ __forceinline__ void ln_body(float* __restrict__ x, const bf16_t* __restrict__ d1,
                                                  const bf16_t* __restrict__ d2, T* __restrict__ y,
                                                  const float* __restrict__ w, const float* __restrict__ b, int rows,
-                                                 float eps, int y_ld, int split, int nt_x, size_t x_lo_off = 0) {
+                                                 float eps, int y_ld, int split, int nt_x, size_t x_lo_off = 0, uint32_t x_bias = 0) {
     constexpr int D = 64 * VEC * NT;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -329,10 +348,10 @@ __device__ __forceinline__ void ln_body(float* __restrict__ x, const bf16_t* __r
     uint8_t* xlo = reinterpret_cast<uint8_t*>(x) + x_lo_off + (size_t)row * D;
     if constexpr (VEC == 4 && sizeof(T) == 2) {
         if (x_lo_off) {
-            r.load_x24(xhi, xlo, lane);
+            r.load_x24(xhi, xlo, lane, x_bias);
             if (d1) r.add_bf16(d1 + (size_t)row * D, lane);
             if (d2) r.add_bf16(d2 + (size_t)row * D, lane);
-            if (WRITE_BACK && (d1 || d2)) r.store_x24(xhi, xlo, lane);
+            if (WRITE_BACK && (d1 || d2)) r.store_x24(xhi, xlo, lane, 0x80u + x_bias);
             r.normalize(w, b, eps, lane);
             r.store(y + (size_t)row * y_ld, lane);
             return;
@@ -366,8 +385,9 @@ template <typename T, int VEC, int NT, bool WRITE_BACK>
 __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const bf16_t* __restrict__ d1,
                                                  const bf16_t* __restrict__ d2, T* __restrict__ y,
                                                  const float* __restrict__ w, const float* __restrict__ b, int rows,
-                                                 float eps, int y_ld, int split, int nt_x = 0, size_t x_lo_off = 0) {
-    ln_body<T, VEC, NT, WRITE_BACK>(x, d1, d2, y, w, b, rows, eps, y_ld, split, nt_x, x_lo_off);
+                                                 float eps, int y_ld, int split, int nt_x = 0, size_t x_lo_off = 0,
+                                                 uint32_t x_bias = 0) {
+    ln_body<T, VEC, NT, WRITE_BACK>(x, d1, d2, y, w, b, rows, eps, y_ld, split, nt_x, x_lo_off, x_bias);
 }
 // token assembly + pre-LN (modeling_clip.py:198-218, :641-651):
 // x[b*S+s] = LN_pre((s == 0 ? cls : patch[b*(S-1)+s-1]) + pos[s])
@@ -375,13 +395,45 @@ template <int VEC, int NT>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
                                                        const float* __restrict__ pos, float* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ b,
-                                                       int rows, int S, float eps, size_t x_lo_off = 0) {
+                                                       int rows, int S, float eps, size_t x_lo_off = 0,
+                                                       float* __restrict__ stats = nullptr, int rows_pad = 0) {
     constexpr int D = 64 * VEC * NT;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    LnRow<VEC, NT> r;
+    if constexpr (VEC == 4) {
+        // stats != nullptr: the LayerNorm-free tower.  x goes out as the planes whose hi plane is bf16(x) (the first q/k/v
+        // GEMM's operand), with {rstd, -mean * rstd} of the row for that GEMM's epilogue; the padding rows up to rows_pad
+        // become zeros in that format (all-zero planes are not: they would read as NaN).
+        if (stats) {
+            if (row >= rows_pad) return;
+            float st_a = 0.0f, st_b = 0.0f;
+            if (row < rows) {
+                const int bimg = row / S, s = row % S;
+                r.load(s == 0 ? cls : patch + ((size_t)bimg * (S - 1) + (s - 1)) * D, lane);
+                r.add(pos + (size_t)s * D, lane);
+                r.normalize(w, b, eps, lane);
+                constexpr float inv = 1.0f / D;
+                float sm = 0.0f;
+#pragma unroll
+                for (int j = 0; j < VEC * NT; ++j) sm += r.v[j];
+                const float mean = wave_sum(sm) * inv;
+                float q = 0.0f;
+#pragma unroll
+                for (int j = 0; j < VEC * NT; ++j) { const float d = r.v[j] - mean; q = __builtin_fmaf(d, d, q); }
+                st_a = 1.0f / sqrtf(wave_sum(q) * inv + eps);
+                st_b = -mean * st_a;
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC * NT; ++j) r.v[j] = 0.0f;
+            }
+            r.store_x24(reinterpret_cast<uint16_t*>(x) + (size_t)row * D, reinterpret_cast<uint8_t*>(x) + x_lo_off + (size_t)row * D, lane, 0x8080u);
+            if (lane == 0) *reinterpret_cast<v2f*>(stats + (size_t)row * 2) = (v2f){st_a, st_b};
+            return;
+        }
+    }
     if (row >= rows) return;
     const int bimg = row / S, s = row % S;
-    LnRow<VEC, NT> r;
     r.load(s == 0 ? cls : patch + ((size_t)bimg * (S - 1) + (s - 1)) * D, lane);
     r.add(pos + (size_t)s * D, lane);
     r.normalize(w, b, eps, lane);
@@ -408,17 +460,17 @@ __global__ void gather_rows_kernel(const T* __restrict__ src, T* __restrict__ ds
 // dst[i * stride_rows][0 .. D) = src[i][0 .. D) with dst row pitch ld elements (the CLS queries of the last layer)
 // dst[i][:] (fp32) = row i * stride_rows of the 24-bit residual stream (two planes, LnRow::load_x24); D a multiple of 4
 __global__ void gather_rows_x24_kernel(const uint16_t* __restrict__ hi, const uint8_t* __restrict__ lo, float* __restrict__ dst, int n,
-                                       size_t stride_rows, int D) {
+                                       size_t stride_rows, int D, uint32_t bias = 0) {
     const size_t total = (size_t)n * (D / 4);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / (D / 4), c = (i % (D / 4)) * 4, src = r * stride_rows * D + c;
         const v2u h = *reinterpret_cast<const v2u*>(hi + src);
         const uint32_t l = *reinterpret_cast<const uint32_t*>(lo + src);
         v4f o;
-        o.x = __uint_as_float((h.x << 16) | ((l & 0xFFu) << 8));
-        o.y = __uint_as_float((h.x & 0xFFFF0000u) | (l & 0xFF00u));
-        o.z = __uint_as_float((h.y << 16) | ((l >> 8) & 0xFF00u));
-        o.w = __uint_as_float((h.y & 0xFFFF0000u) | ((l >> 16) & 0xFF00u));
+        o.x = __uint_as_float(((h.x << 16) | ((l & 0xFFu) << 8)) - bias);
+        o.y = __uint_as_float(((h.x & 0xFFFF0000u) | (l & 0xFF00u)) - bias);
+        o.z = __uint_as_float(((h.y << 16) | ((l >> 8) & 0xFF00u)) - bias);
+        o.w = __uint_as_float(((h.y & 0xFFFF0000u) | ((l >> 16) & 0xFF00u)) - bias);
         *reinterpret_cast<v4f*>(dst + r * D + c) = o;
     }
 }
@@ -641,7 +693,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
                                                    const bf16_t* __restrict__ delta2, const float* __restrict__ w,
                                                    const float* __restrict__ b, const float* __restrict__ proj,
                                                    float* __restrict__ out, int n, int S, int E, float eps,
-                                                   const int* __restrict__ row_of, size_t x_lo_off = 0) {
+                                                   const int* __restrict__ row_of, size_t x_lo_off = 0, uint32_t x_bias = 0) {
     constexpr int D = 64 * VEC * NT, IMG = 8;
     __shared__ float pooled[IMG][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -654,7 +706,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
             bool packed = false;
             if constexpr (VEC == 4) {
                 if (x_lo_off) {   // 24-bit residual in two planes
-                    r.load_x24(reinterpret_cast<const uint16_t*>(x) + row * D, reinterpret_cast<const uint8_t*>(x) + x_lo_off + row * D, lane);
+                    r.load_x24(reinterpret_cast<const uint16_t*>(x) + row * D, reinterpret_cast<const uint8_t*>(x) + x_lo_off + row * D, lane, x_bias);
                     packed = true;
                 }
             }
@@ -1000,6 +1052,73 @@ __device__ __forceinline__ void glds16_buf(rsrc_t r, uint32_t voff, uint32_t sof
                                              0, 0);
 }
 
+
+// ------------------------------------------------------------------ the residual stream of the LayerNorm-free tower
+// 24-bit floats in two planes like LnRow::load_x24, but rounded so that the hi plane IS bf16(x), the operand of the GEMM
+// that follows: b' = bits(x) + 0x8080 (to 24 bits, nearest, plus half a bf16 ulp); hi = b' >> 16 (bf16(x), nearest, ties
+// away from zero), lo = (b' >> 8) & 0xFF; x to 24 bits = ((hi << 16) | (lo << 8)) - 0x8000.  (0.0 is hi = 0, lo = 0x80.)
+constexpr uint32_t X24B_BIAS = 0x8000u;
+template <uint32_t CTRL>
+__device__ __forceinline__ float dpp_movf(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// One step of the EPI_RESID24 epilogue: 8 consecutive columns of one row.  h, l: the old planes (8 x u16, 8 x u8);
+// d: 8 x bf16 of acc + bias.  x_new = x_old + d in fp32; returns the new planes and the lane's sum / sum of squares of
+// x_new.  The ORDER of those sums is part of the contract (whole tiles and quadrant tasks must agree to the bit, and a row
+// must not depend on where it lies): even and odd columns accumulate separately in column order, then even + odd; the
+// caller adds the four lanes of a 32-column block as (l ^ 1) then (l ^ 2).
+__device__ __forceinline__ void resid24_step(const v4u h, const v2u l, const v4u d, v4u& hn, v2u& ln, float& S, float& Q) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // dword i: columns 2i, 2i + 1
+        const uint32_t lw = i < 2 ? l.x : l.y;
+        const uint32_t a = __builtin_amdgcn_perm(h[i], lw, (i & 1) ? 0x0504020Cu : 0x0504000Cu) - X24B_BIAS;
+        const uint32_t b = __builtin_amdgcn_perm(h[i], lw, (i & 1) ? 0x0706030Cu : 0x0706010Cu) - X24B_BIAS;
+        x[2 * i] = __uint_as_float(a) + __uint_as_float(d[i] << 16);
+        x[2 * i + 1] = __uint_as_float(b) + __uint_as_float(d[i] & 0xffff0000u);
+    }
+    v2f s2 = {x[0], x[1]}, q2 = {x[0] * x[0], x[1] * x[1]};
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        const v2f e = {x[2 * i], x[2 * i + 1]};
+        s2 += e;
+        q2 = __builtin_elementwise_fma(e, e, q2);
+    }
+    S = s2.x + s2.y;
+    Q = q2.x + q2.y;
+    uint32_t r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = __float_as_uint(x[i]) + 0x8080u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hn[i] = __builtin_amdgcn_perm(r[2 * i + 1], r[2 * i], 0x07060302u);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t t01 = __builtin_amdgcn_perm(r[4 * i + 1], r[4 * i], 0x0C0C0501u);
+        const uint32_t t23 = __builtin_amdgcn_perm(r[4 * i + 3], r[4 * i + 2], 0x0C0C0501u);
+        ln[i] = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+    }
+}
+
+// partial sums -> {rstd, -mean * rstd} per row: stats[row] = f(sum over the row's D / 32 blocks, in block order).
+// One thread per row (the blocks of a row are 8 * nb contiguous bytes).  var = E[x^2] - mean^2 in fp32 on fp32 partial
+// sums: fine while |mean| is not orders of magnitude above the deviation (a pre-LN residual stream's never is).
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ part, float* __restrict__ stats, int rows, int nb,
+                                                       float inv_d, float eps) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const v4f* p = reinterpret_cast<const v4f*>(part + (size_t)row * nb * 2);
+    float s = 0.0f, q = 0.0f;
+    for (int i = 0; i < nb / 2; ++i) {   // nb is even (D a multiple of 256)
+        const v4f v = p[i];
+        s += v.x; q += v.y;
+        s += v.z; q += v.w;
+    }
+    const float mean = s * inv_d;
+    const float var = fmaxf(q * inv_d - mean * mean, 0.0f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    *reinterpret_cast<v2f*>(stats + (size_t)row * 2) = (v2f){rstd, -mean * rstd};
+}
+
 // ------------------------------------------------------------------ bf16 GEMM, persistent, two staggered wave groups
 // Tile (256 x 256 x 64), LDS image and epilogue as described above; the schedule:
 // the two wave rows (waves 0-3 / 4-7: one wave of each per SIMD) run ONE BARRIER APART, so that in
@@ -1031,10 +1150,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias,
                                                               void* __restrict__ out, int M, int N, int K, int ldo,
-                                                              int n_tiles, int n_full, int order) {
-    static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU, "the persistent form stores bf16 with bias");
+                                                              int n_tiles, int n_full, int order, const PpFold fold = PpFold()) {
+    static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU || EPI == EPI_LNF || EPI == EPI_LNF_QGELU || EPI == EPI_RESID24,
+                  "the persistent form stores bf16 with bias");
     static_assert(sizeof(TO) == 2, "bf16 output");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 128 KiB staging + 18 KiB patches + 2 KiB bias
+    constexpr bool LNF = EPI == EPI_LNF || EPI == EPI_LNF_QGELU;   // LayerNorm folded into this linear (PpFold::cvec, stats)
+    constexpr bool RES = EPI == EPI_RESID24;                        // residual add + row sums in the epilogue (PpFold::xlo, part)
+    constexpr bool GELU = EPI == EPI_BIAS_QGELU || EPI == EPI_LNF_QGELU;
+    // per wave behind the patches: 256 B bias [+ 256 B c + 1 KiB {rstd, -mean rstd} of the wave's 128 rows]
+    constexpr int AUX = LNF ? 1536 : 256;
+    constexpr int AUX_OPS = LNF ? 3 : 1;   // LDS-DMA instructions of stage_aux
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 128 KiB staging + 18 KiB patches + 8 x AUX
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3, g = lane >> 4, l15 = lane & 15;
@@ -1061,10 +1187,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
         glds16_buf(is_x ? xr : wr, x_lane, so, dst);
         glds16_buf(is_x ? xr : wr, x_lane, so + 8u * Kb, dst + 1024);
     };
-    unsigned char* bias_lds = smem + 131072 + 18432 + wave * 256;
-    auto stage_bias = [&](int tn) {
+    unsigned char* bias_lds = smem + 131072 + 18432 + wave * AUX;
+    const rsrc_t cr = make_rsrc(LNF ? fold.cvec : bias, (uint32_t)N * 4u);
+    const rsrc_t sr = make_rsrc(LNF ? fold.stats : bias, LNF ? (uint32_t)M * 8u : 0u);
+    // wave-private: bias (and c) of the wave's 64 columns, and for LNF the row statistics of its 128 rows
+    auto stage_aux = [&](int tm, int tn) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (__attribute__((address_space(3))) void*)bias_lds, 4,
                                                  (uint32_t)lane * 4u, (uint32_t)(tn * 256 + wn * 64) * 4u, 0, 0);
+        if constexpr (LNF) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(cr, (__attribute__((address_space(3))) void*)(bias_lds + 256), 4,
+                                                     (uint32_t)lane * 4u, (uint32_t)(tn * 256 + wn * 64) * 4u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sr, (__attribute__((address_space(3))) void*)(bias_lds + 512), 16,
+                                                     (uint32_t)lane * 16u, (uint32_t)(tm * 256 + wm * 128) * 8u, 0, 0);
+        }
     };
 
     const int sw = lane & 7;
@@ -1131,20 +1266,56 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
     };
     const uint32_t o_lane = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
     unsigned char* patch = smem + 131072 + wave * 2304;
-    // bias + activation + bf16 + 128-byte row segments through the wave's LDS patch; clears acc
+    // EPI_RESID24: the residual planes are updated in place (hi = `out`, bf16 pitch ldo; lo = fold.xlo, byte pitch ldo)
+    const rsrc_t lor = make_rsrc(RES ? (const void*)fold.xlo : (const void*)out, RES ? (uint32_t)M * (uint32_t)ldo : 0u);
+    const int nslot = N / 32;   // 32-column blocks per row of `part`
+    const rsrc_t pr = make_rsrc(RES ? (const void*)fold.part : (const void*)out, RES ? (uint32_t)M * (uint32_t)nslot * 8u : 0u);
+    const int t4 = lane & 3;
+    const uint32_t p_lane = ((uint32_t)(wm * 128 + (t4 >> 1) * 16 + (t4 & 1) * 8 + (lane >> 3)) * (uint32_t)nslot + (uint32_t)(wn * 2 + ((lane >> 2) & 1))) * 8u;
+    // RES_P: steps (8 rows x 64 columns of the wave) whose old planes are in flight ahead of the step being added
+    constexpr int RES_P = 8;
+    // vector-memory instructions an epilogue leaves in the queue behind the operand DMA of the phase it runs in
+    constexpr int EPI_OPS = RES ? 2 * RES_P + 4 : 16;
+    // bias (or the folded LayerNorm) + activation + bf16 + 128-byte row segments through the wave's LDS patch; clears acc
     auto epilogue = [&](int tm, int tn) {
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t o_tile = ((uint32_t)tm * 256u * (uint32_t)ldo + (uint32_t)tn * 256u) * 2u;
         v4f bv[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) bv[ni] = *reinterpret_cast<const v4f*>(bias_lds + (ni * 16 + 4 * g) * 4);
+        v4f cv[4];
+        if constexpr (LNF) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) cv[ni] = *reinterpret_cast<const v4f*>(bias_lds + 256 + (ni * 16 + 4 * g) * 4);
+        }
+        v4u hq[RES_P];
+        v2u lq[RES_P];
+        float ks[4] = {0.0f, 0.0f, 0.0f, 0.0f}, kq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto fetch = [&](int st) {   // old planes of step st = (mi, j): rows mi * 16 + j * 8 + (lane >> 3)
+            const uint32_t so = o_tile + (uint32_t)((st >> 1) * 16 + (st & 1) * 8) * (uint32_t)ldo * 2u;
+            hq[st % RES_P] = __builtin_amdgcn_raw_buffer_load_b128(orr, o_lane, so, 0);
+            lq[st % RES_P] = __builtin_amdgcn_raw_buffer_load_b64(lor, o_lane >> 1, so >> 1, 0);
+        };
+        if constexpr (RES) {   // in step order: the first wait must not stand behind the whole burst
+#pragma unroll
+            for (int st = 0; st < RES_P; ++st) { fetch(st); __builtin_amdgcn_sched_barrier(0); }
+        }
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
+            v2f st2;
+            if constexpr (LNF) st2 = *reinterpret_cast<const v2f*>(bias_lds + 512 + (mi * 16 + l15) * 8);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                v4f v = acc[ni][mi] + bv[ni];
+                v4f v;
+                if constexpr (LNF) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        v[c] = __builtin_fmaf(st2.x, acc[ni][mi][c], __builtin_fmaf(st2.y, cv[ni][c], bv[ni][c]));
+                } else {
+                    v = acc[ni][mi] + bv[ni];
+                }
                 acc[ni][mi] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-                if constexpr (EPI == EPI_BIAS_QGELU) {
+                if constexpr (GELU) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[c] = quick_gelu<true>(v[c]);
                 }
@@ -1160,10 +1331,37 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
                 const int row = j * 8 + (lane >> 3);
                 const v4u d = *reinterpret_cast<const v4u*>(patch + row * 144 + (lane & 7) * 16);
                 const uint32_t so = o_tile + (uint32_t)(mi * 16 + j * 8) * (uint32_t)ldo * 2u;
-                __builtin_amdgcn_raw_buffer_store_b128(d, orr, o_lane, so, 0);
+                if constexpr (RES) {
+                    const int st = 2 * mi + j;
+                    v4u hn; v2u ln; float S, Q;
+                    resid24_step(hq[st % RES_P], lq[st % RES_P], d, hn, ln, S, Q);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_raw_buffer_store_b128(hn, orr, o_lane, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(ln, lor, o_lane >> 1, so >> 1, 0);
+                    if (st + RES_P < 16) fetch(st + RES_P);
+                    S += dpp_movf<0xB1>(S); Q += dpp_movf<0xB1>(Q);   // the four lanes of a 32-column block
+                    S += dpp_movf<0x4E>(S); Q += dpp_movf<0x4E>(Q);
+                    if (t4 == (st & 3)) { ks[st >> 2] = S; kq[st >> 2] = Q; }   // lane t4 of the block keeps steps t4, t4 + 4, ...
+                    // The 16-byte store reads its data registers AFTER it has issued: a VALU write of them in the very next
+                    // instruction (hipcc reused them for a v_pk_mul_f32) reached memory in the last lanes of every row of 16
+                    // (the hazard recogniser pads only stores without an SGPR offset).  Keep them allocated past
+                    // the row sums above.
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("" :: "v"(hn), "v"(ln));
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(d, orr, o_lane, so, 0);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (RES) {
+            // lane t4 holds steps 4u + t4: rows (2u + (t4 >> 1)) * 16 + (t4 & 1) * 8 + (lane >> 3) of the wave's 128
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const v2u pv = {__float_as_uint(ks[u]), __float_as_uint(kq[u])};
+                __builtin_amdgcn_raw_buffer_store_b64(pv, pr, p_lane, (uint32_t)((tm * 256 + 32 * u) * nslot + tn * 8) * 8u, 0);
+            }
         }
     };
 
@@ -1176,7 +1374,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
     if (C.ok) {
         // prologue = the staging of phases -3 .. -1: K tile 0 whole, XH0 WH0 WH1 of K tile 1
         Pos A = advance(C);  // nk >= 2: same tile
-        stage_bias(C.tn);
+        stage_aux(C.tm, C.tn);
 #pragma unroll
         for (int j = 0; j < 4; ++j) stage_half(0, C.xs, C.ws, 0, j);
 #pragma unroll
@@ -1190,7 +1388,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
 // one phase.  READS: this phase's fragment loads; (PK, PB, PJ): the half-tile it stages
 #define PP_WAIT(PK)                                                                   \
     if (!(PK).ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    \
-    else if (relax > 0) { asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); --relax; } \
+    else if (relax > 0) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + EPI_OPS + AUX_OPS) : "memory"); --relax; } \
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #define PP_STAGE(PK, PB, PJ) if ((PK).ok) stage_half(PB, (PK).xs, (PK).ws, (PK).kt, PJ);
         for (;;) {
@@ -1208,7 +1406,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
                 PP_STAGE(A, b ^ 1, 3) PP_WAIT(A)
                 if (wm == 0) PP_BAR
                 epilogue(e_tm, e_tn);
-                stage_bias(C.tn);
+                stage_aux(C.tm, C.tn);
                 relax = 2;
                 load_w(w0f, base, 0); load_w(w1f, base, 1); __builtin_amdgcn_sched_barrier(0); load_x(base, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1233,8 +1431,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
             A = B;
         }
         // last tile of this workgroup: group 0 first (its extra barrier is group 1's last one)
-        if (wm == 0) { epilogue(e_tm, e_tn); PP_BAR }
-        else epilogue(e_tm, e_tn);
+        epilogue(e_tm, e_tn);
+        if (wm == 0) PP_BAR
 #undef PP_WAIT
 #undef PP_STAGE
     }
@@ -1262,7 +1460,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP_BAR
         const uint32_t txs = (uint32_t)ttm * 256u * Kb + 64u * mh * Kb, tws = (uint32_t)ttn * 256u * Kb + 32u * nh * Kb;
-        stage_bias(ttn);
+        stage_aux(ttm, ttn);
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             if (k < nk) stage_task(k, txs, tws, k);
@@ -1279,18 +1477,41 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
             PP_QUADRANT(0, 0, w0f)
         }
         __builtin_amdgcn_sched_barrier(0);
-        v4f bq[2];
+        v4f bq[2], cq[2];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) bq[ni] = *reinterpret_cast<const v4f*>(bias_lds + (32 * nh + ni * 16 + 4 * g) * 4);
+        if constexpr (LNF) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) cq[ni] = *reinterpret_cast<const v4f*>(bias_lds + 256 + (32 * nh + ni * 16 + 4 * g) * 4);
+        }
         const uint32_t q_tile = ((uint32_t)ttm * 256u * (uint32_t)ldo + (uint32_t)(ttn * 256)) * 2u;
         const uint32_t q_lane = ((uint32_t)(wm * 128 + 64 * mh + (lane >> 2)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 32 * nh + 8 * (lane & 3))) * 2u;
+        v4u hq[4];
+        v2u lq[4];
+        if constexpr (RES) {   // the old planes of the task's four 16-row steps
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const uint32_t so = q_tile + (uint32_t)(mi * 16) * (uint32_t)ldo * 2u;
+                hq[mi] = __builtin_amdgcn_raw_buffer_load_b128(orr, q_lane, so, 0);
+                lq[mi] = __builtin_amdgcn_raw_buffer_load_b64(lor, q_lane >> 1, so >> 1, 0);
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
+            v2f st2;
+            if constexpr (LNF) st2 = *reinterpret_cast<const v2f*>(bias_lds + 512 + (64 * mh + mi * 16 + l15) * 8);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                v4f v = acc[ni][mi] + bq[ni];
+                v4f v;
+                if constexpr (LNF) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        v[c] = __builtin_fmaf(st2.x, acc[ni][mi][c], __builtin_fmaf(st2.y, cq[ni][c], bq[ni][c]));
+                } else {
+                    v = acc[ni][mi] + bq[ni];
+                }
                 acc[ni][mi] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-                if constexpr (EPI == EPI_BIAS_QGELU) {
+                if constexpr (GELU) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[c] = quick_gelu<true>(v[c]);
                 }
@@ -1302,7 +1523,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             const v4u d = *reinterpret_cast<const v4u*>(patch + (lane >> 2) * 144 + (lane & 3) * 16);
-            __builtin_amdgcn_raw_buffer_store_b128(d, orr, q_lane, q_tile + (uint32_t)(mi * 16) * (uint32_t)ldo * 2u, 0);
+            const uint32_t so = q_tile + (uint32_t)(mi * 16) * (uint32_t)ldo * 2u;
+            if constexpr (RES) {
+                v4u hn; v2u ln; float S, Q;
+                resid24_step(hq[mi], lq[mi], d, hn, ln, S, Q);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_raw_buffer_store_b128(hn, orr, q_lane, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(ln, lor, q_lane >> 1, so >> 1, 0);
+                S += dpp_movf<0xB1>(S); Q += dpp_movf<0xB1>(Q);
+                S += dpp_movf<0x4E>(S); Q += dpp_movf<0x4E>(Q);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" :: "v"(hn), "v"(ln));   // the store's data registers stay allocated past the sums (see the whole-tile epilogue)
+                // the quad's four lanes hold the block's sums: lane 0 of the quad stores them
+                const uint32_t prow = (uint32_t)(ttm * 256 + wm * 128 + 64 * mh + mi * 16 + (lane >> 2));
+                const v2u pv = {__float_as_uint(S), __float_as_uint(Q)};
+                if (t4 == 0) __builtin_amdgcn_raw_buffer_store_b64(pv, pr, (prow * (uint32_t)nslot + (uint32_t)(ttn * 8 + wn * 2 + nh)) * 8u, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(d, orr, q_lane, so, 0);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -26,6 +26,25 @@ extern "C" {
 int mi_op_linear(int device, int precision, int epilogue, const float* x, const float* w, const float* bias,
                  float* out, size_t m_rows, int n, int k);
 
+/* The two GEMM epilogues of the bf16 tower without LayerNorm kernels (mi_clip_set_option "ln_fold"); bf16 operands,
+ * the persistent kernel only: n % 256 == 0, k % 64 == 0, k >= 128.
+ *
+ * mi_op_linear_lnf: the LayerNorm in front of a linear, finished in its epilogue —
+ *   out[m][j] = act(stats[m][0] * (x w^T)[m][j] + stats[m][1] * c[j] + bias[j]),
+ *   x the UN-normalised rows, w = W diag(gamma), c[j] = sum_k w[j][k], bias = W beta + b, stats[m] = {rstd, -mean rstd};
+ *   epilogue MI_EPI_LNF (act = identity: q/k/v) or MI_EPI_LNF_QGELU (fc1).
+ * mi_op_linear_resid24: the residual add and the row sums in the epilogue —
+ *   xres[m][j] (fp32, in/out; kept as two 24-bit planes around the launch) += bf16(x w^T + bias)[m][j];
+ *   hi_out[m][j] = the hi plane = bf16(new xres), the next GEMM's operand; part[m][n/32][2] = {sum, sum of squares}
+ *   of the new row per 32-column block; stats[m] = {rstd, -mean rstd} from them (ln_stats_kernel).  hi_out, part,
+ *   stats may be NULL. */
+#define MI_EPI_LNF 4
+#define MI_EPI_LNF_QGELU 5
+int mi_op_linear_lnf(int device, int epilogue, const float* x, const float* w, const float* bias, const float* c,
+                     const float* stats, float* out, size_t m_rows, int n, int k);
+int mi_op_linear_resid24(int device, const float* x, const float* w, const float* bias, float* xres, float* hi_out,
+                         float* part, float* stats, size_t m_rows, int n, int k, float eps);
+
 /* softmax(q k^T / 8) v per (image, head): qkv [n_img][s_tok][3*d] (q|k|v, head h =
  * columns h*64..h*64+63 of each third) -> ctx [n_img][s_tok][d]; d == heads*64. */
 int mi_op_attention(int device, int precision, const float* qkv, float* ctx, size_t n_img, int s_tok, int d,
