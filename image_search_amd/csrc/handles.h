@@ -53,7 +53,7 @@ struct mi_clip {
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     bool x24 = true;          // bf16 image tower: the residual stream as 24-bit floats in two planes (3 bytes per element instead of 4; option "x24", MI_CLIP_X24)
-    bool ln_fold = false;     // bf16 image tower without LayerNorm kernels in the layer loop (option "ln_fold", MI_CLIP_LN_FOLD; forward() in vit.hip)
+    bool ln_fold = true;      // bf16 image tower without LayerNorm kernels in the layer loop where the geometry allows (option "ln_fold", MI_CLIP_LN_FOLD; forward() in vit.hip)
     bool fold_ready = false;  // the folded weights were built at load (geometry allows it)
     int parts = 2;  // MI_CLIP_PARTS: sub-chunks run as independent streams
     int n_cu = 256;

@@ -529,7 +529,7 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     const int nb = D / 32;
     auto ln_stats = [&](Part& q) {   // the partial sums of the GEMM just enqueued -> {rstd, -mean rstd} per (padded) row
         const size_t Mp = pad256(q.M);
-        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(Mp / 256)), dim3(256), 0, q.s, q.a->part, q.a->stats, (int)Mp, nb, 1.0f / (float)D, m->eps);
+        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(Mp / 16)), dim3(256), 0, q.s, q.a->part, q.a->stats, (int)Mp, nb, 1.0f / (float)D, m->eps);
         HIP_CHECK(hipGetLastError());
     };
     for (size_t li = 0; li < m->layers.size(); ++li) {
@@ -1275,7 +1275,7 @@ int mi_op_linear_resid24(int device, const float* x, const float* w, const float
         mi_clip mm;
         op_pp_model(mm, device);
         launch_pp<EPI_RESID24>(&mm, dx, dw, db, dhi, mp, n, k, n, f, nullptr);
-        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(mp / 256)), dim3(256), 0, nullptr, f.part, dstats, (int)mp, nb, 1.0f / (float)n, eps);
+        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(mp / 16)), dim3(256), 0, nullptr, f.part, dstats, (int)mp, nb, 1.0f / (float)n, eps);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(hi.data(), dhi, cnt * 2, hipMemcpyDeviceToHost));

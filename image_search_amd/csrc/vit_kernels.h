@@ -1099,24 +1099,30 @@ __device__ __forceinline__ void resid24_step(const v4u h, const v2u l, const v4u
     }
 }
 
-// partial sums -> {rstd, -mean * rstd} per row: stats[row] = f(sum over the row's D / 32 blocks, in block order).
-// One thread per row (the blocks of a row are 8 * nb contiguous bytes).  var = E[x^2] - mean^2 in fp32 on fp32 partial
-// sums: fine while |mean| is not orders of magnitude above the deviation (a pre-LN residual stream's never is).
+// partial sums -> {rstd, -mean * rstd} per row.  16 lanes per row: lane j adds blocks 2j and 2j + 1 of each group of 32
+// blocks (the row's nb * 8 bytes are read as contiguous 16-byte pieces), groups accumulate in order, then the 16 lanes add
+// as a fixed butterfly (l ^ 1, l ^ 2, mirror in 8, mirror in 16) — one order, whatever the launch.
+// var = E[x^2] - mean^2 in fp32 on fp32 partial sums: fine while |mean| is not orders of magnitude above the deviation
+// (a pre-LN residual stream's never is).
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ part, float* __restrict__ stats, int rows, int nb,
                                                        float inv_d, float eps) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= rows) return;
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15;
+    if (row >= rows) return;   // whole 16-lane groups leave together: the DPP adds below stay inside a group
     const v4f* p = reinterpret_cast<const v4f*>(part + (size_t)row * nb * 2);
     float s = 0.0f, q = 0.0f;
-    for (int i = 0; i < nb / 2; ++i) {   // nb is even (D a multiple of 256)
+    for (int i = j; i < nb / 2; i += 16) {   // nb is even (D a multiple of 256)
         const v4f v = p[i];
-        s += v.x; q += v.y;
-        s += v.z; q += v.w;
+        s += v.x + v.z;
+        q += v.y + v.w;
     }
+    s += dpp_movf<0xB1>(s); q += dpp_movf<0xB1>(q);
+    s += dpp_movf<0x4E>(s); q += dpp_movf<0x4E>(q);
+    s += dpp_movf<0x141>(s); q += dpp_movf<0x141>(q);   // row_half_mirror
+    s += dpp_movf<0x140>(s); q += dpp_movf<0x140>(q);   // row_mirror
     const float mean = s * inv_d;
     const float var = fmaxf(q * inv_d - mean * mean, 0.0f);
     const float rstd = 1.0f / sqrtf(var + eps);
-    *reinterpret_cast<v2f*>(stats + (size_t)row * 2) = (v2f){rstd, -mean * rstd};
+    if (j == 0) *reinterpret_cast<v2f*>(stats + (size_t)row * 2) = (v2f){rstd, -mean * rstd};
 }
 
 // ------------------------------------------------------------------ bf16 GEMM, persistent, two staggered wave groups

@@ -112,10 +112,13 @@ int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* nee
  *   "x24"        1 (default) = the bf16 tower keeps its residual stream as 24-bit floats in two planes (16 significant
  *                bits, 3 bytes per element: -14 % LayerNorm traffic, -1 % per forward, error against fp32 unchanged);
  *                0 = fp32 rows.  Neither changes the fp32 parity path or the text tower
- *   "sched"      how the two parts of a forward meet on the chip: 0 (default) = each on its own stream; 1 = all LDS-exclusive
- *                kernels on one stream in a fixed alternation, LayerNorms on a side stream; 2 = blocks chained across the two
- *                streams by events.  "part0_short" = n: the first part n images shorter; "grid_cus" = n: persistent grids capped
- *                at n workgroups.  A/B hooks of round 4: same bits, all slower than the defaults
+ *   "ln_fold"    1 (default) = the bf16 image tower runs layers 0 .. L-2 WITHOUT LayerNorm kernels: gamma is folded into the
+ *                q/k/v and fc1 weights at load, out_proj / fc2 add their output to the residual planes in their own epilogue
+ *                and emit per-row sums, q/k/v / fc1 finish the LayerNorm in theirs (rstd * (acc - mean * c) + b').  Needs
+ *                hidden and intermediate sizes that are multiples of 256 and at least two layers (MI_ERR_UNSUPPORTED when
+ *                set to 1 on another geometry; such handles silently keep the LayerNorm kernels).  0 = LayerNorm kernels
+ *                (rounds 1-4).  -5.7 % per forward; error against fp32 unchanged; a different rounding sequence, so NOT the
+ *                same bits as 0.  "x24" and "ln_nt" only act on the LayerNorm form
  *   "text_fast"  0 = a single text query takes the batched kernels instead of the skinny-GEMM path (text handles) */
 int mi_clip_set_option(mi_clip* m, const char* key, int value);
 

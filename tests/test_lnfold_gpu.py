@@ -62,11 +62,15 @@ def block_sums(x):
 
 
 def stats_of(part, d, eps):
-    s = np.zeros(part.shape[0], F32)
-    q = np.zeros(part.shape[0], F32)
-    for b in range(part.shape[1]):
-        s = (s + part[:, b, 0]).astype(F32)
-        q = (q + part[:, b, 1]).astype(F32)
+    """ln_stats_kernel's order: lane j of 16 adds blocks 2j and 2j + 1, the 16 lanes add as a balanced tree."""
+    m, nb, _ = part.shape
+    assert nb <= 32
+    lanes = np.zeros((m, 16, 2), F32)
+    pair = (part[:, 0::2, :] + part[:, 1::2, :]).astype(F32)
+    lanes[:, :nb // 2] = pair
+    while lanes.shape[1] > 1:
+        lanes = (lanes[:, 0::2] + lanes[:, 1::2]).astype(F32)
+    s, q = lanes[:, 0, 0], lanes[:, 0, 1]
     inv = F32(1.0 / d)
     mean = (s * inv).astype(F32)
     var = np.maximum((q * inv).astype(F32) - (mean * mean).astype(F32), F32(0)).astype(F32)
@@ -204,6 +208,7 @@ def test_mid_tower_ln_fold_within_the_bf16_bound_and_chunking(mid, monkeypatch):
     ref = vit_numpy.vit_forward(w, cfg, px[:6], np.float64)
     rms = float(np.sqrt((ref ** 2).mean()))
     m = Model.from_file(path, 0, PRECISION_BF16)
+    m.set_option("ln_fold", 0)
     base = m.forward(px)
     m.set_option("ln_fold", 1)
     out = m.forward(px)                       # 40 images: two half-chunk streams
@@ -249,6 +254,7 @@ def test_l14_ln_fold_within_the_bf16_bound(built, tmp_path_factory):
     ref = g["embeds_f64"]
     rms = float(np.sqrt((ref ** 2).mean()))
     m = Model.from_file(path, 0, PRECISION_BF16)
+    m.set_option("ln_fold", 0)
     base = m.forward(px)
     m.set_option("ln_fold", 1)
     out = m.forward(px)

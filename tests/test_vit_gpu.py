@@ -460,13 +460,23 @@ def test_persistent_gemm_random_shapes_and_grids(built, monkeypatch, order):
         assert np.array_equal(got, ref), (case, grid, m, n, k)
 
 
-def test_ab_hooks_of_the_bf16_tower_do_not_change_a_bit(l14):
+@pytest.mark.parametrize("ln_fold", [1, 0])
+def test_ab_hooks_of_the_bf16_tower_do_not_change_a_bit(l14, ln_fold):
     """im2col_rows (the LDS-staged patch gather), ln_nt (non-temporal write-back of the residual stream) and gemm_order
-    (which tile a workgroup of the persistent GEMM visits when) move bytes differently, never compute differently: 40 images (two half-chunk streams), every combination, the same bits."""
+    (which tile a workgroup of the persistent GEMM visits when) move bytes differently, never compute differently: 40 images
+    (two half-chunk streams), every combination, the same bits — in the LayerNorm-free layer loop (ln_fold = 1, the default)
+    and in the LayerNorm one.  x24 = 0 (fp32 residual rows under ln_fold = 0) is another rounding, inside the bf16 bound."""
     cfg, w, path, u8, g = l14
     px = synth.preprocess_rgb8(synth.images_u8(78, 40, cfg.image))
     m = Model.from_file(path, 0, PRECISION_BF16)
+    m.set_option("ln_fold", ln_fold)
     ref = m.forward(px)
+    if not ln_fold:
+        m.set_option("x24", 0)
+        o32 = m.forward(px)
+        m.set_option("x24", 1)
+        assert np.abs(o32 - ref).max() <= 3e-2 * float(np.sqrt((ref.astype(np.float64) ** 2).mean()))
+        assert np.array_equal(m.forward(px).view(np.uint32), ref.view(np.uint32))
     for rows_, nt, order in ((0, 0, 4), (0, 1, 0), (1, 3, 3), (1, 0, 8)):
         m.set_option("im2col_rows", rows_)
         m.set_option("ln_nt", nt)
@@ -482,13 +492,15 @@ def test_clock_probe_reads_a_plausible_shader_clock(built):
     assert 300.0 < v.value < 3500.0, v.value
 
 
-@pytest.mark.parametrize("prec", [PRECISION_F32, PRECISION_BF16])
-def test_cls_only_last_layer_is_bit_identical_to_the_full_one(l14, monkeypatch, prec):
+@pytest.mark.parametrize("prec,ln_fold", [(PRECISION_F32, 0), (PRECISION_BF16, 1), (PRECISION_BF16, 0)])
+def test_cls_only_last_layer_is_bit_identical_to_the_full_one(l14, monkeypatch, prec, ln_fold):
     """Behind the last layer's attention only the CLS row is live; computing just that row must give
     the very bits of the full last layer (same per-row arithmetic), for one and for two half-chunks."""
     cfg, w, path, u8, g = l14
     px = synth.preprocess_rgb8(synth.images_u8(77, 40, cfg.image))      # 40 images: two half-chunk streams in bf16
     m = Model.from_file(path, 0, prec)
+    if prec == PRECISION_BF16:
+        m.set_option("ln_fold", ln_fold)
     fast = m.forward(px)
     m.set_option("full_last", 1)
     full = m.forward(px)

@@ -46,7 +46,10 @@ def study(name, weights, cfg, px_index, px_query, ks):
     try:
         e32 = embed(path, px_index, PRECISION_F32)
         q32 = embed(path, px_query, PRECISION_F32)
-        out = [compare(name, "MI_PRECISION_BF16", e32, q32, embed(path, px_index, PRECISION_BF16), embed(path, px_query, PRECISION_BF16), ks),
+        out = [compare(name, "MI_PRECISION_BF16 (default: ln_fold = 1, no LayerNorm kernels in the layer loop)", e32, q32,
+                       embed(path, px_index, PRECISION_BF16, ln_fold=1), embed(path, px_query, PRECISION_BF16, ln_fold=1), ks),
+               compare(name, "MI_PRECISION_BF16 ln_fold = 0 (LayerNorm kernels, the tower of rounds 1-4)", e32, q32,
+                       embed(path, px_index, PRECISION_BF16, ln_fold=0), embed(path, px_query, PRECISION_BF16, ln_fold=0), ks),
                compare(name, "MI_PRECISION_BF16_SPLIT", e32, q32, embed(path, px_index, PRECISION_BF16_SPLIT),
                        embed(path, px_query, PRECISION_BF16_SPLIT), ks)]
     finally:

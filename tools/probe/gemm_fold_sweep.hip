@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
         const unsigned lb = (unsigned)((Mrows + 3) / 4);
         const double l1 = time_us([&] { hipLaunchKernelGGL((ln_kernel<bf16_t, 4, 4, true>), dim3(lb), dim3(256), 0, 0, (float*)xhi, d1, d2, y, lnw, lnw, (int)Mrows, 1e-5f, 1024, 0, 0, Mmax * 1024 * 2, 0u); }, 20);
         const double l2 = time_us([&] { hipLaunchKernelGGL((ln_kernel<bf16_t, 4, 4, false>), dim3(lb), dim3(256), 0, 0, (float*)xhi, d1, (const bf16_t*)nullptr, y, lnw, lnw, (int)Mrows, 1e-5f, 1024, 0, 0, Mmax * 1024 * 2, 0u); }, 20);
-        const double st = time_us([&] { hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(Mp / 256)), dim3(256), 0, 0, part, stats, (int)Mp, 32, 1.0f / 1024, 1e-5f); }, 20);
+        const double st = time_us([&] { hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(Mp / 16)), dim3(256), 0, 0, part, stats, (int)Mp, 32, 1.0f / 1024, 1e-5f); }, 20);
         printf("M=%zu back-to-back us:  qkv %.1f -> LNF %.1f | out %.1f -> RESID24 %.1f | fc1 %.1f -> LNF_QGELU %.1f | fc2 %.1f -> RESID24 %.1f | LN1 %.1f LN2 %.1f stats %.1f\n",
                Mrows, a, b, c, d, e, f, g, h, l1, l2, st);
         printf("M=%zu per layer: GEMMs + LayerNorms today %.1f us; ln_fold %.1f us\n", Mrows, a + c + e + g + l1 + l2, b + d + f + h + 2 * st);

@@ -1,6 +1,6 @@
 """Dev harness (GPU): A/B of the bf16 ViT-L/14 tower at b = 256 inside ONE process and one gpurun call.
 
-  python tools/tower_ab.py sched=0 sched=1 sched=2 [ln_nt=0,sched=1 ...] [--rounds 3] [--reps 10]
+  python tools/tower_ab.py ln_fold=0 ln_fold=1 [ln_fold=1,parts=1 ...] [--rounds 3] [--reps 10]
 
 Every argument is one variant: comma-separated `option=value` pairs applied with mi_clip_set_option on top of
 the defaults.  The variants are timed round-robin (box drift hits them all alike), device-resident input,
@@ -14,14 +14,14 @@ import torch
 from image_search_amd import synth
 from image_search_amd.clip import Model, PRECISION_BF16
 
-DEFAULTS = {"sched": 0, "ln_nt": 0, "split_tail": 1, "parts": 2, "part0_short": 0, "grid_cus": 0, "x24": 1, "gemm_order": 4}
+DEFAULTS = {"ln_fold": 0, "ln_nt": 0, "split_tail": 1, "parts": 2, "x24": 1, "gemm_order": 4}
 
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     def flag(name, dflt):
         return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else dflt
-    args = [a for a in args if "=" in a] or ["sched=0", "sched=1", "sched=2"]
+    args = [a for a in args if "=" in a] or ["ln_fold=0", "ln_fold=1"]
     rounds, reps, n = flag("--rounds", 3), flag("--reps", 10), flag("--n", 256)
     cfg = synth.VitConfig.vit_l14()
     path = os.path.join(tempfile.gettempdir(), f"tower_ab_{os.getpid()}.safetensors")
