@@ -116,6 +116,30 @@ def self_launch(args) -> int:
     return rc
 
 
+def gemm_in_situ(batch):
+    """What the persistent GEMM reaches INSIDE the tower, from the committed rocprofv3 kernel statistics of this command
+    run as ONE stream (profiles/r05_bench_kernel_stats_single_stream.csv: kernel durations add up there; in the
+    two-stream run they overlap) — not an observation of this run.  frac = the four linears' FLOPs / their kernel time."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r05_bench_kernel_stats_single_stream.csv")
+    try:
+        rows = list(csv.DictReader(open(path)))
+    except OSError:
+        return None
+    ns = sum(float(r["TotalDurationNs"]) for r in rows if "gemm_bf16_pp_kernel" in r["Name"])
+    calls = max((int(r["Calls"]) for r in rows if "gemm_bf16_pp_kernel<6" in r["Name"]), default=0)
+    forwards = calls / 46.0 if calls else 0   # EPI_RESID24: out_proj + fc2 of layers 0 .. 22
+    if not forwards or not ns:
+        return None
+    per_forward_ms = ns / forwards / 1e6
+    flop = batch * 257 * 2.0 * (3 * 1024 * 1024 + 1024 * 1024 + 2 * 4096 * 1024) * 23   # the 23 full layers the kernel runs
+    return {"source": "profiles/r05_bench_kernel_stats_single_stream.csv (MI_CLIP_PARTS=1 under rocprofv3 --kernel-trace --stats)",
+            "gemm_ms_per_forward": round(per_forward_ms, 3), "forwards_in_profile": round(forwards, 1),
+            "TFLOP_per_s": round(flop / (per_forward_ms * 1e-3) / 1e12, 1),
+            "frac": round(flop / (per_forward_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "note": "epilogues included: bias, the folded LayerNorm, the residual add and the row sums run inside these kernels"}
+
+
 def cpu_baseline(weights, cfg):
     """The CPU side of the same workload, timed on this host's cores on a bounded sample.  "port": the oracle
     (fixed summation orders: numpy ViT, OpenMP C kNN).  "library": the same two kernels as fast as torch-CPU runs
@@ -253,6 +277,7 @@ def sharded_probe(args) -> int:
         ms = (time.perf_counter() - t0) / 24 * 1e3
         out["knn_ms_per_query" + ("_two_stage" if mode else "")] = round(ms, 4)
     out["rows"] = len(big)
+    out["exchange_cost"] = exchange_cost(args, devices[0])
     # 2. scan task + search handler in the one process: a replica per shard, chunks of n x batch images
     models = [Model.from_file(wpath, d, PRECISION_BF16) for d in (devices if n_dev > 1 else devices[:1])]
     if n_dev <= 1:
@@ -289,6 +314,53 @@ def sharded_probe(args) -> int:
         os.unlink(wpath)
     print("SHARDED_PROBE " + json.dumps(out), flush=True)
     return 0
+
+
+def exchange_cost(args, device):
+    """What the exchange step itself costs, as far as ONE GPU can say: a one-shard table made with
+    the RCCL transport runs the library's real path — ncclAllGather of the packed [k x u64 | k x f32] record on a
+    one-rank communicator + the device merge + the readback — against the same table without an exchange.  Blocking
+    searches (one query per request, server/src/search.rs:70-86), 1 M rows, the two-stage search.  A one-rank
+    all-gather has no wire time: on 8 GPUs the ring adds 7 hops of xGMI latency for 120-byte records."""
+    from image_search_amd import synth
+    from image_search_amd.search import ShardedTable
+
+    qs = synth.corpus_rows(6, 0, 8)
+    res = {}
+    for name, transport in (("no_exchange", None), ("rccl_one_rank", "rccl")):
+        if transport:
+            os.environ["MI_KNN_SHARDED_TRANSPORT"] = transport
+        try:
+            t = ShardedTable(768, [device], args.batch)
+        finally:
+            os.environ.pop("MI_KNN_SHARDED_TRANSPORT", None)
+        t.insert_synthetic(0, 0, 1_000_000)
+        t.set_option("prefilter", 2)
+        for u in range(8):
+            t.knn(qs[u], args.k)
+        lat = []
+        for u in range(64):
+            t0 = time.perf_counter()
+            t.knn(qs[u % 8], args.k)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter()
+        pend = [t.knn_async(qs[u % 8], args.k) for u in range(64)]
+        t.sync()
+        thr = (time.perf_counter() - t0) / 64 * 1e3
+        res[name] = {"transport": t.info()["transport"], "ms_per_blocking_search_median": round(float(np.median(lat)), 4),
+                     "ms_per_blocking_search_min": round(float(np.min(lat)), 4), "ms_per_search_pipelined": round(thr, 4),
+                     "stats": t.stats()}
+        del pend
+        t.close()
+    ex_lat = res["rccl_one_rank"]["ms_per_blocking_search_median"] - res["no_exchange"]["ms_per_blocking_search_median"]
+    ex_thr = res["rccl_one_rank"]["ms_per_search_pipelined"] - res["no_exchange"]["ms_per_search_pipelined"]
+    t_scan = 1.27   # ms: the two-stage scan of one GPU's 10 M rows (BENCH: knn.ms_per_query)
+    res.update({"rows": 1_000_000, "k": args.k,
+                "exchange_ms_blocking": round(ex_lat, 4), "exchange_ms_pipelined": round(ex_thr, 4),
+                "projection_8_gpus": {"t_scan_ms": t_scan, "speedup_blocking": round(8 * t_scan / (t_scan + max(ex_lat, 0.0)), 2),
+                                      "speedup_pipelined": round(8 * t_scan / (t_scan + max(ex_thr, 0.0)), 2),
+                                      "note": "8 t_scan / (t_scan + t_exchange): a PROJECTION from a one-rank collective, unmeasured on > 1 GPU"}})
+    return res
 
 
 def run_sharded_probe(args, wpath):
@@ -616,6 +688,23 @@ def main():
         extra["vit_fp32_b32"] = {"config": "ViT-L/14 image encoder, batch=32 fp32 (exact-f32 MFMA, the parity path), inputs resident",
                                  "ms_per_batch": round(ms, 3), "images_per_sec": round(32e3 / ms, 1), "TFLOP_per_s": round(tf, 1),
                                  "frac_of_f32_mfma_peak": round(tf / PEAK_F32_TFLOPS, 4)}
+        # the parity precision at the headline batch (server/src/clip.rs:112-118 computes in fp32; north_star's 1e-4 holds here)
+        nb = args.batch
+        d_img = torch.from_numpy(np.ascontiguousarray(pins[0].array[:nb])).cuda()
+        d_emb = torch.empty((nb, cfg.proj), dtype=torch.float32, device="cuda")
+        m32.forward_device(d_img.data_ptr(), nb, d_emb.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        a, b = ev(), ev()
+        a.record(stream)
+        for _ in range(2):
+            m32.forward_device(d_img.data_ptr(), nb, d_emb.data_ptr(), stream.cuda_stream)
+        b.record(stream)
+        stream.synchronize()
+        ms = a.elapsed_time(b) / 2
+        tf = nb * VIT_FLOP_PER_IMAGE / (ms * 1e-3) / 1e12
+        extra[f"vit_fp32_b{nb}"] = {"config": f"ViT-L/14 image encoder, batch={nb} fp32 (exact-f32 MFMA, the parity path: <= 1e-4 of the oracle), inputs resident",
+                                    "ms_per_batch": round(ms, 3), "images_per_sec": round(nb * 1e3 / ms, 1), "TFLOP_per_s": round(tf, 1),
+                                    "frac_of_f32_mfma_peak": round(tf / PEAK_F32_TFLOPS, 4)}
         m32.close()
 
     failed = False
@@ -667,12 +756,14 @@ def main():
                             f"two-stage exact ({'byte' if args.prefilter == 2 else 'bf16'} mirror prefilter + fp32 re-evaluation)",
                     "two_stage_equal": two_stage_equal, "fell_back": bool(pref_fell_back),
                     "rows_searched_per_sec": round(world * len(table) / ((ms_knn_two or ms_knn) * 1e-3), 0), "dtype": "f32"},
-            "roofline": {"bound": "mfma", "kernel": "ViT-L/14 forward (gemm_bf16_pp_kernel x 96 + attention + LayerNorm, two half-chunk streams)",
+            "roofline": {"bound": "mfma", "kernel": "ViT-L/14 forward (gemm_bf16_pp_kernel x 96 with the LayerNorms and residual adds in its epilogues + "
+                                                    "attention, two half-chunk streams)",
                          "achieved": round(tf_exec, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf_exec / PEAK_BF16_TFLOPS, 4),
                          "traffic": pmc.get("vit_hbm_bytes") if traffic_ok else None,
                          "traffic_source": "profiles/pmc_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                                            "(tools/round_profile.sh), NOT an observation of this run; fabric-side bytes incl. Infinity-Cache hits",
+                         "gemm_in_situ": gemm_in_situ(args.batch),
                          "executed_gflop_per_image": round(executed / 1e9, 2),
                          "algorithmic_gflop_per_image": round(VIT_FLOP_PER_IMAGE / 1e9, 2),
                          "frac_on_algorithmic_flops": round(tf_alg / PEAK_BF16_TFLOPS, 4),

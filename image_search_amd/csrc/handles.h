@@ -89,6 +89,7 @@ struct mi_clip {
     int gemm_order = 4;       // persistent GEMM tile order: 0 = row-major; np > 0 = column groups of np weight tiles, an XCD's
                               // concurrent tiles a (32 / np) x np patch (N / 256 > np and divisible by it, else row-major)
     bool text_fast = true;    // one text query (n == 1, CLIP-L text geometry, bf16): the skinny-GEMM path (vit.hip forward_text_one)
+    bool text_fuse = true;    // ... with out_proj inside the attention launch (text_attn_out_kernel; option "text_fuse")
     int ln_nt = 0;            // A/B hook (MI_CLIP_LN_NT / option "ln_nt"): bit 0 = LN1 writes the residual stream back non-temporally, bit 1 = LN1's last-use loads non-temporal; measured within noise, off
     bool im2col_rows = true;  // bf16 tower: the LDS-staged patch gather (im2col_rows_kernel); 0 = the 4P-byte-run form (A/B)
     mi::WorkOrder order;          // serialises this handle's enqueued work across caller streams
@@ -131,8 +132,8 @@ struct mi_knn {
     size_t scale8_cap = 0, cfac8_cap = 0, rho8_cap = 0, g8_cap = 0;
     float* d_xx = nullptr;
     bool batch_stage1_mfma = true;  // the shared stage 1 of a group of queries on the matrix pipe (option "batch_stage1")
-    int8_t* d_digits = nullptr;     // [8][3][dim]: the queries of a group as three signed 7-bit digits
-    float* d_qs = nullptr;          // [8][4]: {digit scale S, |q|, rho, -}
+    int8_t* d_digits = nullptr;     // [KNN_GROUP_MAX = 16][3][dim]: the queries of a group as three signed 7-bit digits
+    float* d_qs = nullptr;          // [KNN_GROUP_MAX][4]: {digit scale S, |q|, rho, -}
     size_t digits_cap = 0, qs_cap = 0;
     int pref_sample = 1;            // k <= 64 over the byte mirror: the collect threshold from a sample of the stage-1 keys — 1: for groups of queries, 2: for single queries too, 0: never (option "prefilter_sample")
     uint32_t* d_skeys = nullptr;    // [queries of a group][sample rows]: the keys of every 8th tile, compact

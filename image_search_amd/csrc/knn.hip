@@ -211,7 +211,7 @@ QGroup group_of(const mi_knn* t, uint32_t gy) {
     g.q = t->dim; g.keys = t->cap; g.sel = SEL_WORDS; g.flags = 4; g.rows = (uint64_t)2 * PREF_CAP; g.coll = 4096; g.out = 4096; g.rho = 1;
     return g;
 }
-// nq_batch = 2, 4 or 8 (byte mirror, dim 768): a GROUP of queries, contiguous at d_q: one pass over the mirror writes the
+// nq_batch = 2 .. KNN_GROUP_MAX (16) (byte mirror, dim 768): a GROUP of queries, contiguous at d_q: one pass over the mirror writes the
 // stage-1 keys of all of them, and every later kernel of the search — the selects, the collect, stage 2, the select over the
 // candidates, the sort — runs ONCE for the group with the query as grid.y on per-query copies of the workspaces (QGroup).
 // Returns the fallback word of query 0 (query y: + 4 y).
@@ -480,13 +480,32 @@ void two_stage(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* 
 // nq = 2, 4 or 8 queries (contiguous at d_q) through the two stages with ONE pass over the byte mirror and ONE launch of
 // every later kernel for the whole group (grid.y = query); bit-identical to nq single searches (the per-(row, query)
 // arithmetic of stage 1 is the single kernel's; the selects and stage 2 are the single search's own kernels)
-bool batched_two_stage_applies(const mi_knn* t, uint32_t k) {
-    return t->prefilter == 2 && t->dim == 768 && prefilter_applies(t, k) && !(t->pref_adaptive && (t->pref_skip_left || t->pref_probing));
+// A group counts as ONE search in the feedback of the two-stage search (handles.h: pref_*): it reports its first query's
+// {candidates, fell back} words, it is one of the two probes behind a skip window, and a group of k <= 64 that is sent to
+// the batched single pass instead counts the window down (k > 64 goes through search_one per query, which counts itself).
+bool batched_two_stage_applies(mi_knn* t, uint32_t k) {
+    if (!(t->prefilter == 2 && t->dim == 768 && prefilter_applies(t, k))) return false;
+    if (!t->pref_adaptive) return true;
+    pref_poll(t);
+    if (t->pref_skip_left) {
+        if (k <= 64) {
+            if (--t->pref_skip_left == 0) { t->pref_probing = true; t->pref_probes_left = t->pref_reports_due = 2; t->pref_consec = 0; }
+            ++t->pref_skipped;
+        }
+        return false;
+    }
+    if (t->pref_probing) {
+        if (t->pref_probes_left) { --t->pref_probes_left; return true; }
+        if (k <= 64) ++t->pref_skipped;
+        return false;
+    }
+    return true;
 }
 void search_batched_two_stage(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {
     ensure(t, (void**)&t->d_keys, &t->keys_cap, (size_t)4096 * nq, sizeof(uint64_t));
     t->last_prefiltered = true;
     two_stage(t, d_q, k, d_idx, d_dist, s, nq);
+    if (t->pref_adaptive) pref_record(t, s);   // the group's first query speaks for it (d_pref_flag[0..1])
 }
 
 void search_one(mi_knn* t, const float* d_q, uint32_t k, uint64_t* d_idx, float* d_dist, hipStream_t s) {

@@ -664,6 +664,7 @@ void ensure_text_workspace(mi_clip* m, size_t n) {
         m->act[0].delta = (bf16_t*)bytes(Ma * m->D * 2);
         m->act[0].delta2 = (bf16_t*)bytes(Ma * m->D * 2);
         m->act[0].patch = (float*)bytes((size_t)(m->FF / SKINNY_KC + 1) * SKINNY_ROWS * m->D * 4);  // fc2 partial slabs of forward_text_one
+        m->act[0].col = bytes((size_t)m->H * SKINNY_ROWS * m->D * 4);                                // its per-head out_proj slabs (text_attn_out_kernel)
     }
     m->d_ids = (int*)bytes(Ma * sizeof(int));
     m->d_rows = (int*)bytes(n * sizeof(int));
@@ -693,19 +694,30 @@ void forward_text_one(mi_clip* m, hipStream_t s) {
     const float* b2 = nullptr;
     const int* ids = m->d_ids;      // first layer: LN1 also assembles x = token + position embeddings
     int n_slabs = 0;
+    // out_proj inside the attention launch (option "text_fuse", default): every head's contribution arrives as an fp32 slab
+    // and LN2 lands their sum (+ bias) in the residual stream — one launch less per layer, no bf16 rounding of the delta
+    const bool fuse = m->text_fuse && D % (16 * TAO_NT) == 0 && S <= SKINNY_ROWS;
+    float* oslabs = (float*)a.col;  // [H][SKINNY_ROWS][D] fp32
     for (const Layer& ly : m->layers) {
         // LN1 also lands the previous layer's residual adds: x += out_proj delta + fc2 partial sums + fc2 bias
         hipLaunchKernelGGL((ln_slab_kernel<VEC, NT>), dim3(lb), dim3(256), 0, s, a.x, d1, slabs, n_slabs, b2, y, ly.ln1w, ly.ln1b, S, m->eps, 1,
                            ids, m->tok, m->pos);
         ids = nullptr;
         hipLaunchKernelGGL((skinny_gemm_kernel<SKINNY_BIAS>), dim3(3 * D / 16, 1), dim3(256), 0, s, y, D, (const bf16_t*)ly.wqkv, D, ly.bqkv, qkv, 3 * D);
-        attention(m, qkv, y, 1, s);
-        hipLaunchKernelGGL((skinny_gemm_kernel<SKINNY_BIAS>), dim3(D / 16, 1), dim3(256), 0, s, y, D, (const bf16_t*)ly.wo, D, ly.bo, a.delta, D);
-        hipLaunchKernelGGL((ln_slab_kernel<VEC, NT>), dim3(lb), dim3(256), 0, s, a.x, a.delta, slabs, 0, nullptr, y, ly.ln2w, ly.ln2b, S, m->eps, 0,
-                           (const int*)nullptr, (const float*)nullptr, (const float*)nullptr);
+        if (fuse) {
+            constexpr int SP = 96;
+            hipLaunchKernelGGL((text_attn_out_kernel<SP>), dim3(m->H, D / (16 * TAO_NT)), dim3(64 * TAO_WAVES), SP * 256, s, qkv, (const bf16_t*)ly.wo, oslabs, S, D, 1);
+            hipLaunchKernelGGL((ln_slab_kernel<VEC, NT>), dim3(lb), dim3(256), 0, s, a.x, (const bf16_t*)nullptr, oslabs, m->H, ly.bo, y, ly.ln2w, ly.ln2b, S, m->eps, 1,
+                               (const int*)nullptr, (const float*)nullptr, (const float*)nullptr);
+        } else {
+            attention(m, qkv, y, 1, s);
+            hipLaunchKernelGGL((skinny_gemm_kernel<SKINNY_BIAS>), dim3(D / 16, 1), dim3(256), 0, s, y, D, (const bf16_t*)ly.wo, D, ly.bo, a.delta, D);
+            hipLaunchKernelGGL((ln_slab_kernel<VEC, NT>), dim3(lb), dim3(256), 0, s, a.x, a.delta, slabs, 0, nullptr, y, ly.ln2w, ly.ln2b, S, m->eps, 0,
+                               (const int*)nullptr, (const float*)nullptr, (const float*)nullptr);
+        }
         hipLaunchKernelGGL((skinny_gemm_kernel<SKINNY_BIAS_QGELU>), dim3(FF / 16, 1), dim3(256), 0, s, y, D, (const bf16_t*)ly.w1, D, ly.b1, h, FF);
         hipLaunchKernelGGL((skinny_gemm_kernel<SKINNY_SLAB>), dim3(D / 16, FF / SKINNY_KC), dim3(256), 0, s, h, FF, (const bf16_t*)ly.w2, FF, nullptr, slabs, D);
-        d1 = a.delta; b2 = ly.b2; n_slabs = FF / SKINNY_KC;
+        d1 = fuse ? nullptr : a.delta; b2 = ly.b2; n_slabs = FF / SKINNY_KC;
     }
     // the EOS row: the last layer's residual adds, final_layer_norm and the projection, fp32, one launch
     hipLaunchKernelGGL((text_head_one_kernel<VEC, NT>), dim3((unsigned)((m->E + 3) / 4)), dim3(256), 0, s, a.x, d1, slabs, n_slabs, b2, m->post_w,
@@ -856,6 +868,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         }
         else if (k == "im2col_rows") m->im2col_rows = value != 0;
         else if (k == "text_fast") m->text_fast = value != 0;
+        else if (k == "text_fuse") m->text_fuse = value != 0;
         else if (k == "ln_nt") m->ln_nt = value & 3;
         else if (k == "x24") m->x24 = value != 0;   // takes effect with the next forward (every forward rewrites the residual stream)
         else if (k == "ln_fold") {   // takes effect with the next forward (every forward rewrites the residual stream)
@@ -876,7 +889,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, text_fuse, max_batch, parts)", key);
     });
 }
 

@@ -578,7 +578,19 @@ struct LnSlabRow {
             r.load(x + (size_t)row * D, lane);
         }
         if (d1) r.add_bf16(d1 + (size_t)row * D, lane);
-        for (int s = 0; s < n_slabs; ++s) r.add(slabs + ((size_t)s * SKINNY_ROWS + row) * D, lane);
+        int s = 0;
+        for (; s + 4 <= n_slabs; s += 4) {   // four slabs' loads in flight at a time, added in slab order
+            float u[4][VEC * NT];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ld_vec<VEC>(&u[j][t * VEC], slabs + ((size_t)(s + j) * SKINNY_ROWS + row) * D + (t * 64 + lane) * VEC);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < VEC * NT; ++i) r.v[i] += u[j][i];
+        }
+        for (; s < n_slabs; ++s) r.add(slabs + ((size_t)s * SKINNY_ROWS + row) * D, lane);
         if (n_slabs) r.add(bias2, lane);
     }
     // LnRow::normalize with w and b already in registers
@@ -1279,7 +1291,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
     const int t4 = lane & 3;
     const uint32_t p_lane = ((uint32_t)(wm * 128 + (t4 >> 1) * 16 + (t4 & 1) * 8 + (lane >> 3)) * (uint32_t)nslot + (uint32_t)(wn * 2 + ((lane >> 2) & 1))) * 8u;
     // RES_P: steps (8 rows x 64 columns of the wave) whose old planes are in flight ahead of the step being added
-    constexpr int RES_P = 8;
+#ifndef MI_RES_P
+#define MI_RES_P 8   // probe builds sweep it (tools/probe/gemm_fold_sweep.hip -DMI_RES_P=n): 4 / 8 / 12 read within noise of one another
+#endif
+    constexpr int RES_P = MI_RES_P;
     // vector-memory instructions an epilogue leaves in the queue behind the operand DMA of the phase it runs in
     constexpr int EPI_OPS = RES ? 2 * RES_P + 4 : 16;
     // bias (or the folded LayerNorm) + activation + bf16 + 128-byte row segments through the wave's LDS patch; clears acc
@@ -1663,10 +1678,12 @@ __device__ __forceinline__ float xmax_rows(float v) {
 // are only two waves per SIMD and the chain MFMA -> max -> exp -> pack -> MFMA is latency-bound
 // (measured: no overlap between the two resident waves), so the second tile supplies the
 // independent instructions; the K and V fragments read from LDS serve both tiles.
-template <int S_PAD, int S_CT, int NQ>
-__device__ __forceinline__ void attn_tiles(const unsigned char* __restrict__ Ks, const unsigned char* __restrict__ Vs,
-                                           const bf16_t* __restrict__ base, bf16_t* __restrict__ ctx_b, size_t ld,
-                                           int S_rt, int D, const int (&qt)[NQ], int lane, int causal = 0) {
+// emit(u, query row, d0, d1): the context row of tile u's query l15 as bf16 — d0 = head dims 8g .. 8g + 7, d1 = 32 + 8g ..
+// (which is also the B-operand fragment pair of an MFMA 16x16x32 over the head's 64 dims: text_attn_out_kernel)
+template <int S_PAD, int S_CT, int NQ, class Emit>
+__device__ __forceinline__ void attn_tiles_epi(const unsigned char* __restrict__ Ks, const unsigned char* __restrict__ Vs,
+                                               const bf16_t* __restrict__ base, size_t ld, int S_rt, const int (&qt)[NQ], int lane,
+                                               int causal, Emit&& emit) {
     constexpr int NKT = S_PAD / 16, NPV = S_PAD / 32;
     const int S = S_CT > 0 ? S_CT : S_rt;
     const int g = lane >> 4, l15 = lane & 15;
@@ -1789,19 +1806,30 @@ __device__ __forceinline__ void attn_tiles(const unsigned char* __restrict__ Ks,
     for (int u = 0; u < NQ; ++u) {
         const int qi = qt[u] * 16 + l15;
         const float ie = __builtin_amdgcn_rcpf(osum[u][0]);
+        v4u d[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            d[w].x = pack2bf(o[u][2 * w][0] * ie, o[u][2 * w][1] * ie);
+            d[w].y = pack2bf(o[u][2 * w][2] * ie, o[u][2 * w][3] * ie);
+            d[w].z = pack2bf(o[u][2 * w + 1][0] * ie, o[u][2 * w + 1][1] * ie);
+            d[w].w = pack2bf(o[u][2 * w + 1][2] * ie, o[u][2 * w + 1][3] * ie);
+        }
+        emit(u, qi, d[0], d[1]);
+    }
+}
+template <int S_PAD, int S_CT, int NQ>
+__device__ __forceinline__ void attn_tiles(const unsigned char* __restrict__ Ks, const unsigned char* __restrict__ Vs,
+                                           const bf16_t* __restrict__ base, bf16_t* __restrict__ ctx_b, size_t ld,
+                                           int S_rt, int D, const int (&qt)[NQ], int lane, int causal = 0) {
+    const int S = S_CT > 0 ? S_CT : S_rt;
+    const int g = lane >> 4;
+    attn_tiles_epi<S_PAD, S_CT, NQ>(Ks, Vs, base, ld, S_rt, qt, lane, causal, [&](int, int qi, v4u d0, v4u d1) {
         if (qi < S) {
             bf16_t* dst = ctx_b + (size_t)qi * D + 8 * g;
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                v4u d;
-                d.x = pack2bf(o[u][2 * w][0] * ie, o[u][2 * w][1] * ie);
-                d.y = pack2bf(o[u][2 * w][2] * ie, o[u][2 * w][3] * ie);
-                d.z = pack2bf(o[u][2 * w + 1][0] * ie, o[u][2 * w + 1][1] * ie);
-                d.w = pack2bf(o[u][2 * w + 1][2] * ie, o[u][2 * w + 1][3] * ie);
-                *reinterpret_cast<v4u*>(dst + 32 * w) = d;
-            }
+            *reinterpret_cast<v4u*>(dst) = d0;
+            *reinterpret_cast<v4u*>(dst + 32) = d1;
         }
-    }
+    });
 }
 
 // Two query tiles A, B software-pipelined inside one wave, written in the order the wave should
@@ -2026,6 +2054,60 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (q0 < nqt) {
         const int one[1] = {q0};
         attn_tiles<S_PAD, S_CT, 1>(Ks, Vs, base, ctx_b, ld, S_rt, D, one, lane, causal);
+    }
+}
+
+// ------------------------------------------------------------------ one text query: attention + out_proj in one launch
+// forward_text_one's attention followed by its out_proj: the context rows of a head come out of attn_tiles_epi as the very
+// B-operand fragments an MFMA over the head's 64 dims wants, so out_proj's contribution of that head,
+//   slab[h][row][n] = sum_{d < 64} ctx_h[row][d] * Wo[n][64 h + d]      (fp32, SKINNY_ROWS rows per slab)
+// needs no memory round trip; ln_slab_kernel adds the H slabs in head order (+ bias) into the residual stream.
+// grid = (H, N / (16 * TAO_NT)): every workgroup redoes its head's (tiny: 77 x 77 x 64) attention and owns TAO_NT
+// 16-column tiles of the output, whose weight fragments are requested before anything else.
+constexpr int TAO_NT = 12, TAO_WAVES = 5;   // a wave per 16-query tile: 80 positions in one sweep (four waves left one of them two tiles)
+template <int S_PAD>
+__global__ __launch_bounds__(64 * TAO_WAVES) void text_attn_out_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ Wo,
+                                                            float* __restrict__ slabs, int S, int D, int causal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;
+    unsigned char* Vs = smem + S_PAD * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = blockIdx.x, n0 = blockIdx.y * 16 * TAO_NT;
+    const int g = lane >> 4, l15 = lane & 15;
+    const size_t ld = (size_t)3 * D;
+    const bf16_t* base = qkv + hh * 64;
+    bf16x8 afr[TAO_NT][2];
+#pragma unroll
+    for (int nt = 0; nt < TAO_NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            afr[nt][ks] = *reinterpret_cast<const bf16x8*>(Wo + (size_t)(n0 + 16 * nt + l15) * D + hh * 64 + 32 * ks + 8 * g);
+    {
+        const rsrc_t kvr = make_rsrc(base, (uint32_t)((size_t)S * ld * 2 - (size_t)hh * 128));
+        const int rr = lane >> 3, p = lane & 7;
+        const uint32_t voff = (uint32_t)rr * (uint32_t)(ld * 2) + 16u * (uint32_t)(p ^ rr);
+        for (int j = __builtin_amdgcn_readfirstlane(wave); j < S_PAD / 8; j += TAO_WAVES) {
+            const uint32_t so = (uint32_t)(8 * j) * (uint32_t)(ld * 2);
+            glds16_buf(kvr, voff, so + (uint32_t)D * 2u, Ks + j * 1024);
+            glds16_buf(kvr, voff, so + (uint32_t)D * 4u, Vs + j * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    float* slab = slabs + (size_t)hh * SKINNY_ROWS * D + n0;
+    for (int q0 = wave; q0 < (S + 15) / 16; q0 += TAO_WAVES) {
+        const int one[1] = {q0};
+        attn_tiles_epi<S_PAD, 0, 1>(Ks, Vs, base, ld, S, one, lane, causal, [&](int, int, v4u d0, v4u d1) {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, d0), b1 = __builtin_bit_cast(bf16x8, d1);
+#pragma unroll
+            for (int nt = 0; nt < TAO_NT; ++nt) {
+                v4f acc = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[nt][0], b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[nt][1], b1, acc, 0, 0, 0);
+                // acc[e] = slab[row q0 * 16 + l15][n0 + 16 nt + 4 g + e]; rows S .. SKINNY_ROWS - 1 hold the padding queries' values, never read
+                *reinterpret_cast<v4f*>(slab + (size_t)(q0 * 16 + l15) * D + 16 * nt + 4 * g) = acc;
+            }
+        });
     }
 }
 

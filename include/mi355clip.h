@@ -119,7 +119,9 @@ int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* nee
  *                set to 1 on another geometry; such handles silently keep the LayerNorm kernels).  0 = LayerNorm kernels
  *                (rounds 1-4).  -5.7 % per forward; error against fp32 unchanged; a different rounding sequence, so NOT the
  *                same bits as 0.  "x24" and "ln_nt" only act on the LayerNorm form
- *   "text_fast"  0 = a single text query takes the batched kernels instead of the skinny-GEMM path (text handles) */
+ *   "text_fast"  0 = a single text query takes the batched kernels instead of the skinny-GEMM path (text handles)
+ *   "text_fuse"  0 = on that path, attention and out_proj as two launches with a bf16 delta between them (rounds 2-4);
+ *                1 (default) = one launch per layer, the heads' out_proj contributions summed in fp32 by the LayerNorm */
 int mi_clip_set_option(mi_clip* m, const char* key, int value);
 
 /* geometry of a loaded model: out[0..7] = image, patch, tokens, hidden, layers,
@@ -260,7 +262,10 @@ int mi_knn_search_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, u
  * group of up to 16 queries shares one pass over the byte mirror on the matrix pipe (the queries cut into three signed 7-bit
  * digits, exact int8 MFMA dot products; option "batch_stage1" = 0: the vector-ALU form, groups of 8 / 4 / 2) and ONE launch
  * of every later kernel of the two-stage search; otherwise passes of 8 / 4 / 2 queries over the fp32 rows (k <= 64).
- * Results identical to nq calls of mi_knn_search_device with nq = 1: same ids, same distance bits. */
+ * Results identical to nq calls of mi_knn_search_device with nq = 1: same ids, same distance bits.
+ * Device memory: a group keeps per-query copies of the two-stage workspaces, allocated by the first group of that size
+ * and kept — per query 4 bytes per table row (stage-1 keys: 640 MB for 16 queries over 10 M rows, 6.4 GB over 100 M),
+ * 32 MB of candidate rows + keys, and the select / sort buffers; a failed allocation fails that search with MI_ERR_OOM. */
 int mi_knn_search_batched_device(mi_knn* t, const float* d_q, uint32_t nq, uint32_t k, uint64_t* d_idx,
                                  float* d_dist, void* stream);
 

@@ -221,8 +221,50 @@ def test_full_size_10m_matches_oracle_and_properties(built, orc):
                 cand, fell_back = t.prefilter_stats()
                 _same(gi, gd, *want[u, k])
                 assert k <= cand < (1 << 22) and not fell_back, (mode, k, cand, fell_back)
+    # GROUPS of queries at this size (the int8-MFMA stage 1 shared by the group, per-query workspaces for everything behind
+    # it): one group of 16 and one of 5 whose members 0 and 1 are the two queries the oracle answered — ids and distance
+    # bits of orc_knn, through the two stages, stage 1 on the matrix pipe (1) and on the vector ALU (0)
+    t.set_option("prefilter", 2)
+    rng = np.random.default_rng(5)
+    for nq in (16, 5):
+        group = np.concatenate([qs[:2], rng.standard_normal((nq - 2, 768)).astype(np.float32)])
+        for stage1 in (1, 0):
+            t.set_option("batch_stage1", stage1)
+            for k in (10, 1000):
+                gi, gd = t.knn(group, k)
+                cand, fell_back = t.prefilter_stats()
+                assert not fell_back, (nq, stage1, k, cand)
+                for u in range(2):
+                    _same(gi[u], gd[u], *want[u, k])
+                for u in range(2, nq):   # the other members: sorted, distinct, distances recomputed from the returned rows
+                    assert np.all(np.diff(gd[u]) >= 0) and len(set(gi[u].tolist())) == k
+                    rid = int(gi[u][0])
+                    assert orc_cosine_dist(orc, group[u], synth.corpus_rows(0, rid, 1))[0] == gd[u][0]
+    t.set_option("batch_stage1", 1)
     # ... and the single pass at the reference's K
     t.set_option("prefilter", 0)
     gi, gd = t.knn(qs[0], 1000)
     _same(gi, gd, *want[0, 1000])
     t.close()
+
+
+def test_groups_through_the_sharded_table_match_the_oracle(built, orc):
+    """The same groups through mi_knn_sharded (three shards on one device, block-cyclic rows, the exchange and the device
+    merge behind every shard's group search): 1 M rows against orc_knn — ids and distance bits."""
+    from image_search_amd.search import ShardedTable
+    n = 1_000_000
+    sh = ShardedTable(768, [0, 0, 0])
+    sh.insert_synthetic(0, 0, n)
+    sh.set_option("prefilter", 2)
+    qs = synth.corpus_rows(1, 0, 16)
+    rows = orc_gen_f32(orc, 0, 0, n * 768).reshape(n, 768)
+    want = {(u, k): orc_knn(orc, qs[u], rows, k) for u in range(2) for k in (10, 1000)}
+    del rows
+    for nq in (16, 5):
+        for k in (10, 1000):
+            gi, gd = sh.knn(qs[:nq], k)
+            for u in range(2):
+                _same(gi[u], gd[u], *want[u, k])
+            for u in range(2, nq):
+                assert np.all(np.diff(gd[u]) >= 0) and len(set(gi[u].tolist())) == k
+    sh.close()

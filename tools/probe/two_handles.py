@@ -1,6 +1,6 @@
 import json, os, sys, tempfile
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from image_search_amd import synth
 from image_search_amd.clip import Model, PRECISION_BF16

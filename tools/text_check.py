@@ -30,6 +30,13 @@ for pname, prec in (("fp32", PRECISION_F32), ("bf16", PRECISION_BF16)):
             for _ in range(50):
                 m.embed(ids)
             print(f"bf16 n=1 text_fast={fast}: {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms per call")
+        for fuse in (0, 1, 0, 1):
+            m.set_option("text_fuse", fuse)
+            m.embed(ids); m.embed(ids); m.embed(ids)
+            t0 = time.perf_counter()
+            for _ in range(200):
+                m.embed(ids)
+            print(f"bf16 n=1 text_fuse={fuse}: {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms per call ({'73' if fuse else '85'} launches in the graph)")
     else:
         m.close()
 m = TextModel.from_file(path)
