@@ -89,6 +89,7 @@ struct mi_clip {
     int gemm_order = 4;       // persistent GEMM tile order: 0 = row-major; np > 0 = column groups of np weight tiles, an XCD's
                               // concurrent tiles a (32 / np) x np patch (N / 256 > np and divisible by it, else row-major)
     bool text_fast = true;    // one text query (n == 1, CLIP-L text geometry, bf16): the skinny-GEMM path (vit.hip forward_text_one)
+    bool attn_f32_mfma = true; // fp32 attention for S <= 272 on the matrix pipe (attn_f32_mfma_kernel); 0 = one thread per query (A/B; option "attn_f32_mfma")
     bool text_fuse = true;    // ... with out_proj inside the attention launch (text_attn_out_kernel; option "text_fuse")
     int ln_nt = 0;            // A/B hook (MI_CLIP_LN_NT / option "ln_nt"): bit 0 = LN1 writes the residual stream back non-temporally, bit 1 = LN1's last-use loads non-temporal; measured within noise, off
     bool im2col_rows = true;  // bf16 tower: the LDS-staged patch gather (im2col_rows_kernel); 0 = the 4P-byte-run form (A/B)

@@ -390,9 +390,22 @@ void layer_norm(mi_clip* m, float* x, const bf16_t* d1, const bf16_t* d2, bool w
 // first_tile_only: only the leading query tile / block of every (image, head) -- it holds the CLS row
 void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, bool first_tile_only = false) {
     if (m->precision == MI_PRECISION_F32) {
-        const int qb = first_tile_only ? 1 : (m->S + 63) / 64;
-        const unsigned blocks = (unsigned)(n * m->H * qb);
-        hipLaunchKernelGGL(attn_f32_kernel, dim3(blocks), dim3(64), 0, s, (const float*)qkv, (float*)ctx, m->S, m->D, m->H, m->text ? 1 : 0, first_tile_only ? 1 : 0);
+        if (m->S <= 272 && m->attn_f32_mfma) {   // on the matrix pipe (exact-f32 MFMA), one workgroup per (image, head)
+#define MI_ATTNF(SP)                                                                                                    \
+    {                                                                                                                   \
+        static DevOnce once;                                                                                            \
+        allow_lds_once(once, attn_f32_mfma_kernel<SP>, attnf_lds_bytes(SP));                                            \
+        hipLaunchKernelGGL((attn_f32_mfma_kernel<SP>), dim3((unsigned)(n * m->H)), dim3(512), attnf_lds_bytes(SP), s, (const float*)qkv, (float*)ctx, m->S, m->D, m->H, m->text ? 1 : 0, first_tile_only ? 1 : 0); \
+    }
+            if (m->S <= 80) MI_ATTNF(80)          // the text tower's 77 positions; ViT-B/32
+            else if (m->S <= 208) MI_ATTNF(208)   // ViT-B/16 @224
+            else MI_ATTNF(272)                    // ViT-L/14, ViT-H/14 @224
+#undef MI_ATTNF
+        } else {
+            const int qb = first_tile_only ? 1 : (m->S + 63) / 64;
+            const unsigned blocks = (unsigned)(n * m->H * qb);
+            hipLaunchKernelGGL(attn_f32_kernel, dim3(blocks), dim3(64), 0, s, (const float*)qkv, (float*)ctx, m->S, m->D, m->H, m->text ? 1 : 0, first_tile_only ? 1 : 0);
+        }
     } else if (m->attn_ver >= 2 && !m->text && m->S > 64 && m->S <= 288) {
 #define MI_ATTN32(SP, SC)                                                                                              \
     {                                                                                                                  \
@@ -869,6 +882,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         else if (k == "im2col_rows") m->im2col_rows = value != 0;
         else if (k == "text_fast") m->text_fast = value != 0;
         else if (k == "text_fuse") m->text_fuse = value != 0;
+        else if (k == "attn_f32_mfma") m->attn_f32_mfma = value != 0;
         else if (k == "ln_nt") m->ln_nt = value & 3;
         else if (k == "x24") m->x24 = value != 0;   // takes effect with the next forward (every forward rewrites the residual stream)
         else if (k == "ln_fold") {   // takes effect with the next forward (every forward rewrites the residual stream)
@@ -889,7 +903,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, text_fuse, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, text_fuse, attn_f32_mfma, max_batch, parts)", key);
     });
 }
 
@@ -1313,6 +1327,7 @@ int mi_op_attention(int device, int precision, const float* qkv, float* ctx, siz
         m.precision = precision; m.S = s_tok; m.D = d; m.H = heads;
         if (const char* e = std::getenv("MI_OP_ATTN")) m.attn_ver = std::atoi(e) == 1 ? 1 : 2;   // test hook: which bf16 kernel
         if (const char* e = std::getenv("MI_OP_ATTN_SHIFT")) m.attn_shift = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MI_OP_ATTN_F32_MFMA")) m.attn_f32_mfma = std::atoi(e) != 0;   // test hook: 0 = the one-thread-per-query fp32 kernel
         const size_t rows = n_img * s_tok;
         void* dq = sc.up(precision, qkv, rows, 3 * (size_t)d, pad256(rows));
         void* dc = sc.bytes(pad256(rows) * d * 4);

@@ -1654,6 +1654,129 @@ __device__ __forceinline__ float xmax_rows(float v) {
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
+// ------------------------------------------------------------------ attention, fp32 on the matrix pipe (parity path, S <= 272)
+// The one-thread-per-query kernel above was 21 % of the fp32 forward at b = 256 for 4 % of its FLOPs (3.6 ms per layer).
+// Same softmax, exact-f32 MFMA 16x16x4: one workgroup of 8 waves per (image, head), K and V of the head as fp32 rows in LDS
+// (pitch 68 floats: 16 consecutive rows start in 16 different bank quads), a wave per 16-query tile.
+//   S^T = K Q^T:  A = K[key 16T + l15][16g + kk], B = q[query l15][16g + kk] (q already times 1/8) over kk = 0..15 — the
+//                 MFMA's k index is a dummy, so lane group g takes the CONTIGUOUS dims 16g .. 16g+15 (four ds_read_b128
+//                 per key tile) instead of the strided ones;  sc[T][e] = s[key 16T + 4g + e][query l15]
+//   softmax:      max / sum over a lane's 4 * NKT scores, then over the four lane groups (xmax_rows / xsum_rows)
+//   O^T = V^T P^T: for the same reason key slot (e, g) of an MFMA means key 16T + 4g + e, so the B operand is the lane's OWN
+//                 p[T][e] — P never moves — and A = V[16T + 4g + e][16dt + l15];  o[dt][e'] = O[query l15][16dt + 4g + e']
+// causal / q_tiles as attn_f32_kernel (q_tiles counts 16-query tiles here).
+__device__ __forceinline__ float xsum_rows(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned w = __float_as_uint(v);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+constexpr int ATTNF_PITCH = 68;
+constexpr int attnf_lds_bytes(int s_pad) { return 2 * s_pad * ATTNF_PITCH * 4; }
+template <int S_PAD>
+__global__ __launch_bounds__(512) void attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int S, int D, int H,
+                                                            int causal, int q_tiles) {
+    constexpr int NKT = S_PAD / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* Ks = reinterpret_cast<float*>(smem);
+    float* Vs = Ks + S_PAD * ATTNF_PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.x / H, hh = blockIdx.x % H;
+    const size_t ld = (size_t)3 * D;
+    const float* base = qkv + (size_t)b * S * ld + hh * 64;
+    for (int idx = tid; idx < S_PAD * 16; idx += 512) {
+        const int row = idx >> 4, c4 = (idx & 15) * 4;
+        v4f kv = {0.0f, 0.0f, 0.0f, 0.0f}, vv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (row < S) {
+            kv = *reinterpret_cast<const v4f*>(base + (size_t)row * ld + D + c4);
+            vv = *reinterpret_cast<const v4f*>(base + (size_t)row * ld + 2 * D + c4);
+        }
+        *reinterpret_cast<v4f*>(Ks + row * ATTNF_PITCH + c4) = kv;
+        *reinterpret_cast<v4f*>(Vs + row * ATTNF_PITCH + c4) = vv;
+    }
+    __syncthreads();
+    const int nkt_all = (S + 15) / 16;
+    const int nqt = q_tiles > 0 ? min(q_tiles, nkt_all) : nkt_all;
+    for (int qt = wave; qt < nqt; qt += 8) {
+        const int qi = qt * 16 + l15;
+        const int qc = qi < S ? qi : S - 1;
+        const int nkt = causal ? min(nkt_all, qt + 1) : nkt_all;   // causal: key tiles beyond the diagonal one are all masked
+        float qf[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const v4f t = *reinterpret_cast<const v4f*>(base + (size_t)qc * ld + 16 * g + 4 * i);
+            qf[4 * i] = t.x * 0.125f; qf[4 * i + 1] = t.y * 0.125f; qf[4 * i + 2] = t.z * 0.125f; qf[4 * i + 3] = t.w * 0.125f;
+        }
+        v4f sc[NKT];
+#pragma unroll
+        for (int T = 0; T < NKT; ++T) {
+            sc[T] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+            if (T < nkt) {
+                float kf[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const v4f t = *reinterpret_cast<const v4f*>(Ks + (16 * T + l15) * ATTNF_PITCH + 16 * g + 4 * i);
+                    kf[4 * i] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) sc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kk], qf[kk], sc[T], 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int T = 0; T < NKT; ++T) {
+            if (T < nkt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = 16 * T + 4 * g + e;
+                    if (key >= S || (causal && key > qc)) sc[T][e] = -INFINITY;
+                    mx = fmaxf(mx, sc[T][e]);
+                }
+            }
+        }
+        mx = xmax_rows(mx);
+        float l = 0.0f;
+#pragma unroll
+        for (int T = 0; T < NKT; ++T) {
+            if (T < nkt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pw = expf(sc[T][e] - mx);   // exp(-inf) = 0 for the masked keys
+                    sc[T][e] = pw;
+                    l += pw;
+                }
+            }
+        }
+        l = xsum_rows(l);
+        v4f o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int T = 0; T < NKT; ++T) {
+            if (T < nkt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float* vrow = Vs + (16 * T + 4 * g + e) * ATTNF_PITCH + l15;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[16 * dt], sc[T][e], o[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (qi < S) {
+            float* dst = ctx + ((size_t)b * S + qi) * D + hh * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const v4f t = {o[dt][0] / l, o[dt][1] / l, o[dt][2] / l, o[dt][3] / l};
+                *reinterpret_cast<v4f*>(dst + 16 * dt) = t;
+            }
+        }
+    }
+}
+
+
 // ------------------------------------------------------------------ attention, bf16 MFMA
 // One workgroup per (image, head); K and V of the head ([S_PAD][64] bf16, 128-byte
 // rows, 16-byte chunks XOR-swizzled with row&7) stay in LDS; each wave walks query

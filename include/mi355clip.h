@@ -119,6 +119,8 @@ int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* nee
  *                set to 1 on another geometry; such handles silently keep the LayerNorm kernels).  0 = LayerNorm kernels
  *                (rounds 1-4).  -5.7 % per forward; error against fp32 unchanged; a different rounding sequence, so NOT the
  *                same bits as 0.  "x24" and "ln_nt" only act on the LayerNorm form
+ *   "attn_f32_mfma" 0 = the fp32 path's attention as one thread per query (rounds 1-4) instead of the exact-f32 MFMA kernel
+ *                (another summation order, both far inside 1e-4; A/B hook)
  *   "text_fast"  0 = a single text query takes the batched kernels instead of the skinny-GEMM path (text handles)
  *   "text_fuse"  0 = on that path, attention and out_proj as two launches with a bf16 delta between them (rounds 2-4);
  *                1 (default) = one launch per layer, the heads' out_proj contributions summed in fp32 by the LayerNorm */

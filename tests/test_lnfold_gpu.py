@@ -195,9 +195,11 @@ def _model(tmp, cfg, seed=3):
     return w, path
 
 
-@pytest.fixture(scope="module")
-def mid(built, tmp_path_factory):
-    cfg = synth.VitConfig(hidden=256, layers=4, heads=4, ff=512, patch=14, image=56, proj=64)
+@pytest.fixture(scope="module", params=["d256", "d768"])
+def mid(built, tmp_path_factory, request):
+    # 256: one weight tile per row of out_proj / fc2 (8 sum blocks per row); 768: three (24 blocks; ViT-B's width)
+    cfg = (synth.VitConfig(hidden=256, layers=4, heads=4, ff=512, patch=14, image=56, proj=64) if request.param == "d256" else
+           synth.VitConfig(hidden=768, layers=3, heads=12, ff=1024, patch=14, image=56, proj=64))
     w, path = _model(tmp_path_factory.mktemp("w"), cfg)
     return cfg, w, path
 
@@ -229,6 +231,23 @@ def test_mid_tower_ln_fold_within_the_bf16_bound_and_chunking(mid, monkeypatch):
     for key, val in (("full_last", 0), ("gemm_order", 4), ("split_tail", 1), ("parts", 2)):
         m.set_option(key, val)
     assert np.array_equal(m.forward(px).view(np.uint32), base.view(np.uint32))
+    m.close()
+
+
+def test_a_nan_in_one_image_stays_a_nan_and_stays_in_that_image(mid):
+    """The residual planes carry NaN / Inf patterns through their encode / decode (an integer add on the bit pattern), the row
+    statistics of a poisoned row are NaN, and nothing of it may reach another image of the batch."""
+    cfg, w, path = mid
+    px = synth.preprocess_rgb8(synth.images_u8(203, 40, cfg.image))
+    m = Model.from_file(path, 0, PRECISION_BF16)
+    clean = m.forward(px)
+    bad = px.copy()
+    bad[3, 1, 20, 20] = np.nan
+    bad[25, 0, 5, 7] = np.inf
+    out = m.forward(bad)
+    assert np.isnan(out[3]).all() and np.isnan(out[25]).all()
+    keep = [i for i in range(40) if i not in (3, 25)]
+    assert np.array_equal(out[keep].view(np.uint32), clean[keep].view(np.uint32))
     m.close()
 
 

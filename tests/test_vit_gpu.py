@@ -123,6 +123,27 @@ def test_attention(built, prec, tol, S):
     assert np.abs(ops.attention(qkv, H, prec) - ref).max() <= tol * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("S", [5, 16, 77, 80, 81, 197, 208, 257, 272, 273])
+def test_attention_fp32_on_the_matrix_pipe_and_one_thread_per_query_agree(built, monkeypatch, S):
+    """The parity path's attention runs on exact-f32 MFMAs for S <= 272 (attn_f32_mfma_kernel: LDS images of 80 / 208 / 272
+    key rows) and one thread per query beyond: both against numpy fp64 at 5e-6, on both sides of every size boundary, with a
+    sharply peaked query and a partly masked last key tile."""
+    rng = np.random.default_rng(300 + S)
+    n, H = 2, 2
+    D = 64 * H
+    qkv = rng.standard_normal((n, S, 3 * D)).astype(np.float32)
+    qkv[0, S // 2, :D] *= 6.0
+    q, k, v = [qkv[..., i * D:(i + 1) * D].reshape(n, S, H, 64).transpose(0, 2, 1, 3).astype(np.float64) for i in range(3)]
+    sc = q @ k.transpose(0, 1, 3, 2) * 0.125
+    p = np.exp(sc - sc.max(-1, keepdims=True))
+    ref = (p / p.sum(-1, keepdims=True) @ v).transpose(0, 2, 1, 3).reshape(n, S, D)
+    got = ops.attention(qkv, H, PRECISION_F32)
+    assert np.abs(got - ref).max() <= 5e-6 * np.abs(ref).max()
+    monkeypatch.setenv("MI_OP_ATTN_F32_MFMA", "0")
+    old = ops.attention(qkv, H, PRECISION_F32)
+    assert np.abs(old - ref).max() <= 5e-6 * np.abs(ref).max()
+
+
 def _peaked_qkv(S, n, H, beta, gamma, seed):
     """Query i attends to exactly one key pi(i): keys are random +-1 codes (dims 8..63) plus a common
     component (dims 0..7 = +1); q_i = beta * code(pi(i)) - gamma * common.  Scores (natural units):
