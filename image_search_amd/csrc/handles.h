@@ -49,6 +49,7 @@ struct mi_clip {
         // ln_fold: per-row partial sums written by the out_proj / fc2 epilogues [M][D / 32][2] and what the q/k/v / fc1
         // epilogues read, {rstd, -mean * rstd} [M][2]
         float *part = nullptr, *stats = nullptr;
+        float* c_stats = nullptr;   // ... of the CLS rows (last layer: the query columns are computed for those rows only)
     } act[4];
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};

@@ -219,9 +219,9 @@ void load_layers(mi_clip* m, WeightFile& st, const std::string& v) {
         const std::vector<float> w1 = st.read(p + "mlp.fc1.weight", (int64_t)FF * D), b1 = st.read(p + "mlp.fc1.bias", FF);
         ly.w1 = upload_mat(m, w1, m->split_ln ? (size_t)D : 0);
         ly.b1 = upload_f32(m, b1);
-        if (m->fold_ready && i + 1 < L) {  // the last layer keeps its LayerNorm kernels (forward())
+        if (m->fold_ready) {  // (the last layer folds LN1 only: behind its attention it works on the CLS rows, forward())
             fold_ln(m, wqkv, bqkv, st.read(p + "layer_norm1.weight", D), st.read(p + "layer_norm1.bias", D), 3 * D, D, &ly.wqkv_f, &ly.cqkv, &ly.bqkv_f);
-            fold_ln(m, w1, b1, st.read(p + "layer_norm2.weight", D), st.read(p + "layer_norm2.bias", D), FF, D, &ly.w1_f, &ly.c1, &ly.b1_f);
+            if (i + 1 < L) fold_ln(m, w1, b1, st.read(p + "layer_norm2.weight", D), st.read(p + "layer_norm2.bias", D), FF, D, &ly.w1_f, &ly.c1, &ly.b1_f);
         }
         ly.w2 = upload_mat(m, st.read(p + "mlp.fc2.weight", (int64_t)D * FF));
         ly.b2 = upload_f32(m, st.read(p + "mlp.fc2.bias", D));
@@ -276,6 +276,7 @@ void ensure_workspace(mi_clip* m, size_t n) {
         if (m->fold_ready) {
             m->act[a].part = (float*)bytes(Ma * (size_t)(m->D / 32) * 8);
             m->act[a].stats = (float*)bytes(Ma * 8);
+            m->act[a].c_stats = (float*)bytes(Ca * 8);
         }
     }
     (void)Mp; (void)Pp;
@@ -552,7 +553,8 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
         // ---- LN1, q/k/v, attention of every part; then the rest of every part
         for (int p = 0; p < parts; ++p) {
             Part& q = pt[p];
-            if (lnf) {
+            if (fold && last) continue;   // LN1 folded into the K / V and CLS-query GEMMs below
+            if (fold) {   // every layer's LN1 is folded, the last one's too (its LN2 is not: it runs on the CLS rows)
                 PpFold f;
                 f.cvec = ly.cqkv; f.stats = q.a->stats;
                 launch_pp<EPI_LNF>(m, q.a->x, ly.wqkv_f, ly.bqkv_f, q.a->qkv, pad256(q.M), 3 * D, D, 3 * D, f, q.s);
@@ -576,18 +578,31 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
                 f1.cvec = ly.c1; f1.stats = q.a->stats;
                 launch_pp<EPI_LNF_QGELU>(m, q.a->x, ly.w1_f, ly.b1_f, q.a->h, pad256(q.M), FF, D, FF, f1, s);
                 launch_pp<EPI_RESID24>(m, q.a->h, ly.w2, ly.b2, q.a->x, pad256(q.M), D, FF, D, f, s);
-                if (li + 2 < m->layers.size()) ln_stats(q);   // the last layer's LayerNorm kernel reads the planes themselves
+                ln_stats(q);
                 continue;
             }
             if (last) {
                 // keys and values of every token, queries of the CLS rows only (the other rows of the
                 // leading query tile keep whatever the buffer held: their context rows are never read)
                 const size_t es = esize(m);
-                gemm<EPI_BIAS>(m, q.a->y, (const char*)ly.wqkv + (size_t)D * Kln * es, ly.bqkv + D, (char*)q.a->qkv + (size_t)D * es, q.M, 2 * D, Kln, 3 * D, s);
                 const unsigned gb = (unsigned)std::min<size_t>((q.n * (size_t)D / 4 + 255) / 256, 4096);
+                if (fold) {
+                    // the same EPI_LNF arithmetic as the full layer's q/k/v launch, so the same bits: K | V columns of every
+                    // row from the hi plane, and the CLS rows' hi-plane rows + statistics gathered for the query columns
+                    PpFold f;
+                    f.cvec = ly.cqkv + D; f.stats = q.a->stats;
+                    launch_pp<EPI_LNF>(m, q.a->x, (const char*)ly.wqkv_f + (size_t)D * D * 2, ly.bqkv_f + D, (char*)q.a->qkv + (size_t)D * 2, pad256(q.M), 2 * D, D, 3 * D, f, s);
+                    hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, (const bf16_t*)q.a->x, (bf16_t*)q.a->c_y, (int)q.n, (size_t)S, D);
+                    hipLaunchKernelGGL(gather_stats_kernel, dim3((unsigned)((q.n + 255) / 256)), dim3(256), 0, s, q.a->stats, q.a->c_stats, (int)q.n, (size_t)S);
+                    PpFold fq;
+                    fq.cvec = ly.cqkv; fq.stats = q.a->c_stats;
+                    launch_pp<EPI_LNF>(m, q.a->c_y, ly.wqkv_f, ly.bqkv_f, q.a->c_ctx, pad256(q.n), D, D, D, fq, s);
+                } else {
+                gemm<EPI_BIAS>(m, q.a->y, (const char*)ly.wqkv + (size_t)D * Kln * es, ly.bqkv + D, (char*)q.a->qkv + (size_t)D * es, q.M, 2 * D, Kln, 3 * D, s);
                 if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_y, (int)q.n, (size_t)S, Kln);
                 else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb), dim3(256), 0, s, (const float*)q.a->y, (float*)q.a->c_y, (int)q.n, (size_t)S, D);
                 gemm<EPI_BIAS>(m, q.a->c_y, ly.wqkv, ly.bqkv, q.a->c_ctx, q.n, D, Kln, D, s);
+                }
                 if (deferred) hipLaunchKernelGGL((scatter_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, (const bf16_t*)q.a->c_ctx, (bf16_t*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)3 * D);
                 else hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3(gb), dim3(256), 0, s, (const float*)q.a->c_ctx, (float*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)3 * D);
                 HIP_CHECK(hipGetLastError());

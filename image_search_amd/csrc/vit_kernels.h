@@ -474,6 +474,11 @@ __global__ void gather_rows_x24_kernel(const uint16_t* __restrict__ hi, const ui
         *reinterpret_cast<v4f*>(dst + r * D + c) = o;
     }
 }
+// dst[i] = stats[i * stride_rows] ({rstd, -mean rstd} of the CLS rows: the last layer's query GEMM runs on those rows only)
+__global__ void gather_stats_kernel(const float* __restrict__ stats, float* __restrict__ dst, int n, size_t stride_rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) *reinterpret_cast<v2f*>(dst + (size_t)i * 2) = *reinterpret_cast<const v2f*>(stats + (size_t)i * stride_rows * 2);
+}
 template <typename T>
 __global__ void scatter_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, size_t stride_rows, int D, size_t ld) {
     const int per = D * (int)sizeof(T) / 16;

@@ -104,6 +104,28 @@ def test_resid24_epilogue_exact_on_integers(built, monkeypatch, grid, shape):
     assert np.allclose(stats, stats_of(pw, n, 1e-5), rtol=2e-6, atol=0)
 
 
+def test_resid24_epilogue_race_screen_at_the_tower_shapes(built):
+    """The tower's own out_proj / fc2 shapes (half chunk: 129 row tiles x 4 column tiles, a split last round on all 256
+    workgroups), integer operands so that every bit is known, 12 repetitions each: a stale plane, a prefetched row arriving
+    late or a store reading a reused register would show as a changed word in some repetition."""
+    rng = np.random.default_rng(21)
+    for (m, n, k) in ((32896, 1024, 1024), (32896, 1024, 4096)):
+        x = rng.integers(-1, 2, (m, k)).astype(F32)
+        w = (rng.integers(-1, 2, (n, k)) * (rng.random((n, k)) < 0.05)).astype(F32)   # sparse: |acc| stays far below 256
+        b = rng.integers(-3, 4, n).astype(F32)
+        res = (rng.integers(-4000, 4001, (m, n)) / 16).astype(F32)
+        delta = x @ w.T + b
+        assert np.abs(delta).max() <= 256
+        want = (res + delta).astype(F32)
+        hi_w, lo_w = enc24(want)
+        want_bits = dec24(hi_w, lo_w).view(np.uint32)
+        pw = block_sums(want).view(np.uint32)
+        for rep in range(12):
+            got, hi, part, stats = ops.linear_resid24(x, w, b, res)
+            assert np.array_equal(got.view(np.uint32), want_bits), (m, n, k, rep)
+            assert np.array_equal(part.view(np.uint32), pw), (m, n, k, rep)
+
+
 def test_resid24_epilogue_random_data_and_rounding(built):
     """Random operands: the delta is the bf16 of an fp32 accumulation (its order is the MFMA's), so compare within one
     bf16 ulp of the delta; the hi plane must be bf16(new x) to nearest and the planes must reproduce x to 24 bits."""

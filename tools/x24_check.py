@@ -12,6 +12,7 @@ synth.save_safetensors(w, path, {"num_attention_heads": cfg.heads})
 px = synth.preprocess_rgb8(synth.images_u8(int(g["image_seed"]), int(g["n_img"]), cfg.image))
 ref = g["embeds_f64"]; rms = float(np.sqrt((ref ** 2).mean()))
 m = Model.from_file(path, 0, PRECISION_BF16); os.unlink(path)
+m.set_option("ln_fold", 0)   # x24 is the residual format of the LayerNorm-kernel form of the layer loop (round 5: ln_fold = 1 by default has its own planes)
 out = {}
 for v in (0, 1):
     m.set_option("x24", v)
