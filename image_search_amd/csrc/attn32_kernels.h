@@ -471,7 +471,8 @@ __host__ __device__ constexpr int attn32_lds_bytes(int s_pad) { return 2 * (2 * 
 #define ATTN32_BARRIER { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); }
 template <int S_PAD, int S_CT, bool PRESCALED>
 __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int S_rt,
-                                                             int D, int H, int n_pairs, int cls_only, int force_shift) {
+                                                             int D, int H, int n_pairs, int cls_only, int force_shift,
+                                                             int pair_order, int ld_qkv, int ld_ctx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int IMG = 2 * S_PAD * 128;  // K then V
     constexpr int NPIECE = S_PAD / 8;     // 1-KiB DMA pieces per matrix
@@ -480,7 +481,10 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
     const int S = S_CT > 0 ? S_CT : S_rt;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t ld = (size_t)3 * D;
+    // row pitches in elements: qkv rows may be padded beyond 3 D, ctx rows beyond D.  Dense qkv rows (6 144 bytes at
+    // D = 1024) put the 128-byte K / V / q pieces of a head on few memory channels: the kernel ran 15-20 % longer, and a
+    // quarter longer still on the heads 3 and 11 (tools/probe/attn_clock.hip; mi_clip pads the tower's qkv rows)
+    const size_t ld = (size_t)ld_qkv, ldc = (size_t)ld_ctx;
     const int r = lane & 31, h = lane >> 5;
     const int G = gridDim.x;
 
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         const int img = __builtin_amdgcn_readfirstlane(pr / H), hh = __builtin_amdgcn_readfirstlane(pr - img * H);
         Pair q;
         q.base = qkv + (size_t)img * S * ld + hh * 64;
-        q.ctx_b = ctx + (size_t)img * S * D + hh * 64;
+        q.ctx_b = ctx + (size_t)img * S * ldc + hh * 64;
         q.bytes = (uint32_t)((size_t)S * ld * 2 - (size_t)hh * 128);
         return q;
     };
@@ -552,10 +556,17 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         const int dt = lane >> 5, w32 = lane & 31, hh = (w32 >> 2) & 1, reg = (w32 & 3) + 4 * (w32 >> 3);
         float acc = 0.0f;
         for (int t = 0; t < 9; ++t) acc += wgt[t] * part[(t * 2 + hh) * ATTN32_PROW + dt * 16 + reg];
-        ctx_prev[(size_t)split_row * D + lane] = f2bf(acc / lt);
+        ctx_prev[(size_t)split_row * ldc + lane] = f2bf(acc / lt);
     };
 
-    int pair = blockIdx.x;
+    // The first pair of workgroup b (it then walks first, first + G, ...).  Blocks b, b + 8, ... share an XCD (round-robin
+    // dispatch, tools/probe/xcc_probe.hip), and with first = b every one of an XCD's 32 workgroups sits on the two heads
+    // b % 8 and b % 8 + 8 for the whole launch: K / V rows 6 144 bytes apart at two fixed column offsets, i.e. a quarter of
+    // that XCD's L2 channels — measured: the workgroups of one slot (b % 8 == 3 on every box) took 25 % more cycles than
+    // the rest and the launch waited for them.  pair_order 1 transposes the start: slot s of XCD x begins at pair
+    // x * G / 8 + s, so the workgroups that share an L2 work on all 16 heads of two images at any one time.
+    const int first = (pair_order == 1 && (G & 7) == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int pair = first;
     if (pair >= n_pairs) return;
     ATTN32_STAMP_BEGIN
     Pair cur = pair_of(pair);
@@ -641,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
                 attn32_sweep<S_CT, true>(Ks, Vs, qa, negm == INFINITY ? 0.0f : negm, S_rt, 0, 1, lane, o, l, dma_hook);
             }
             while (more && piece < NPIECE) dma_hook();  // pieces the sweep had no step for: in front of the stores (vmcnt order)
-            attn32_store(o, 1.0f / l, cur.ctx_b, 32 * qt + r, 32 * qt + r < S, D, lane);
+            attn32_store(o, 1.0f / l, cur.ctx_b, 32 * qt + r, 32 * qt + r < S, (int)ldc, lane);
         }
         while (more && piece < NPIECE) dma_hook();  // a wave without a whole tile issues its pieces here
         ATTN32_STAMP(3)   // whole tile: sweep + store
@@ -667,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
     if (split) {  // the last pair's split query
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         ATTN32_BARRIER
-        const int last_it = (n_pairs - 1 - (int)blockIdx.x) / G;
+        const int last_it = (n_pairs - 1 - first) / G;
         if (wave == 1) combine(scratch + (last_it & 1) * ATTN32_PART, ctx_prev);
     }
     ATTN32_STAMP_END

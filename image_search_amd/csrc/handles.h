@@ -85,6 +85,8 @@ struct mi_clip {
     int attn_ver = 2;         // bf16 attention for 64 < S <= 288: 2 = 32-query tiles (attn32_kernels.h), 1 = 16-query tiles
     bool q_prescaled = false; // log2(e)/8 folded into W_q / b_q at load (attn_ver 2 in the tower)
     bool attn_shift = false;  // force the shifted (exact maximum) pass of attn32 — test hook
+    int qkv_pad = 128;        // elements added to the image tower's qkv row pitch where attn32 runs (vit.hip: qkv_pitch)
+    int attn_order = 1;       // attn32: first pair of workgroup b (0 = b; 1 = transposed, an XCD's workgroups spread over all heads)
     bool full_last = false;   // compute the dead rows of the last layer too (A/B against the reference graph)
     bool split_tail = true;   // cut a short last round of GEMM tiles into quadrant tasks
     int gemm_order = 4;       // persistent GEMM tile order: 0 = row-major; np > 0 = column groups of np weight tiles, an XCD's

@@ -38,6 +38,15 @@ size_t esize(const mi_clip* m) { return m->precision == MI_PRECISION_F32 ? 4 : 2
 
 size_t pad256(size_t v) { return (v + 255) / 256 * 256; }
 
+// Row pitch (elements) of the image tower's qkv buffer.  Where the persistent attn32 kernel runs, rows are padded by
+// option "qkv_pad" elements (default 128 = 256 bytes; a multiple of 64 so that the GEMM epilogue still stores whole
+// 128-byte lines): dense 6 144-byte rows put a head's K / V / q pieces on few memory channels and cost that kernel 15-20 %.
+bool attn32_applies(const mi_clip* m) {
+    return m->precision != MI_PRECISION_F32 && m->attn_ver >= 2 && !m->text && m->S > 64 && m->S <= 288;
+}
+size_t qkv_pitch(const mi_clip* m) { return (size_t)3 * m->D + (attn32_applies(m) ? (size_t)m->qkv_pad : 0); }
+
+
 template <typename T>
 T* dalloc(mi_clip* m, size_t n, std::vector<void*>& bag) {
     void* p = nullptr;
@@ -262,7 +271,7 @@ void ensure_workspace(mi_clip* m, size_t n) {
         m->act[a].patch = (float*)bytes(Pa * m->D * 4);
         m->act[a].x = (float*)bytes(Ma * m->D * 4);
         m->act[a].y = bytes(Ma * m->D * es * (m->split_ln ? 2 : 1));
-        m->act[a].qkv = bytes(Ma * 3 * m->D * es);
+        m->act[a].qkv = bytes(Ma * qkv_pitch(m) * es);
         m->act[a].h = bytes(Ma * m->FF * es);
         m->act[a].delta = (bf16_t*)bytes(Ma * m->D * 2);
         m->act[a].delta2 = (bf16_t*)bytes(Ma * m->D * 2);
@@ -389,7 +398,8 @@ void layer_norm(mi_clip* m, float* x, const bf16_t* d1, const bf16_t* d2, bool w
 }
 
 // first_tile_only: only the leading query tile / block of every (image, head) -- it holds the CLS row
-void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, bool first_tile_only = false) {
+void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, bool first_tile_only = false, int ld_qkv = 0) {
+    if (ld_qkv == 0) ld_qkv = 3 * m->D;
     if (m->precision == MI_PRECISION_F32) {
         if (m->S <= 272 && m->attn_f32_mfma) {   // on the matrix pipe (exact-f32 MFMA), one workgroup per (image, head)
 #define MI_ATTNF(SP)                                                                                                    \
@@ -407,7 +417,7 @@ void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, 
             const unsigned blocks = (unsigned)(n * m->H * qb);
             hipLaunchKernelGGL(attn_f32_kernel, dim3(blocks), dim3(64), 0, s, (const float*)qkv, (float*)ctx, m->S, m->D, m->H, m->text ? 1 : 0, first_tile_only ? 1 : 0);
         }
-    } else if (m->attn_ver >= 2 && !m->text && m->S > 64 && m->S <= 288) {
+    } else if (attn32_applies(m)) {
 #define MI_ATTN32(SP, SC)                                                                                              \
     {                                                                                                                  \
         constexpr int LDS = attn32_lds_bytes(SP);                                                                      \
@@ -415,10 +425,10 @@ void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, 
         const int pairs = (int)(n * m->H), grid = std::min(pairs, m->n_cu);                                            \
         if (m->q_prescaled) {                                                                                          \
             allow_lds_once(once[1], attn32_bf16_kernel<SP, SC, true>, LDS);                                            \
-            hipLaunchKernelGGL((attn32_bf16_kernel<SP, SC, true>), dim3(grid), dim3(512), LDS, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, pairs, first_tile_only ? 1 : 0, m->attn_shift ? 1 : 0); \
+            hipLaunchKernelGGL((attn32_bf16_kernel<SP, SC, true>), dim3(grid), dim3(512), LDS, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, pairs, first_tile_only ? 1 : 0, m->attn_shift ? 1 : 0, m->attn_order, ld_qkv, m->D); \
         } else {                                                                                                       \
             allow_lds_once(once[0], attn32_bf16_kernel<SP, SC, false>, LDS);                                           \
-            hipLaunchKernelGGL((attn32_bf16_kernel<SP, SC, false>), dim3(grid), dim3(512), LDS, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, pairs, first_tile_only ? 1 : 0, m->attn_shift ? 1 : 0); \
+            hipLaunchKernelGGL((attn32_bf16_kernel<SP, SC, false>), dim3(grid), dim3(512), LDS, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, pairs, first_tile_only ? 1 : 0, m->attn_shift ? 1 : 0, m->attn_order, ld_qkv, m->D); \
         }                                                                                                              \
     }
         if (m->S == 257) MI_ATTN32(288, 257)       // ViT-L/14, ViT-H/14 @224
@@ -541,6 +551,7 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     // graph computes the other rows and discards them).  Option "full_last" keeps the full last layer.
     const bool full_last = m->full_last;
     const int nb = D / 32;
+    const int ldq = (int)qkv_pitch(m);   // row pitch of qkv (padded where attn32 runs)
     auto ln_stats = [&](Part& q) {   // the partial sums of the GEMM just enqueued -> {rstd, -mean rstd} per (padded) row
         const size_t Mp = pad256(q.M);
         hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(Mp / 16)), dim3(256), 0, q.s, q.a->part, q.a->stats, (int)Mp, nb, 1.0f / (float)D, m->eps);
@@ -557,14 +568,14 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
             if (fold) {   // every layer's LN1 is folded, the last one's too (its LN2 is not: it runs on the CLS rows)
                 PpFold f;
                 f.cvec = ly.cqkv; f.stats = q.a->stats;
-                launch_pp<EPI_LNF>(m, q.a->x, ly.wqkv_f, ly.bqkv_f, q.a->qkv, pad256(q.M), 3 * D, D, 3 * D, f, q.s);
-                attention(m, q.a->qkv, q.a->y, q.n, q.s, false);
+                launch_pp<EPI_LNF>(m, q.a->x, ly.wqkv_f, ly.bqkv_f, q.a->qkv, pad256(q.M), 3 * D, D, ldq, f, q.s);
+                attention(m, q.a->qkv, q.a->y, q.n, q.s, false, ldq);
                 continue;
             }
             layer_norm_x(m, q.a->x, q.p1, q.p2, true, q.a->y, ly.ln1w, ly.ln1b, q.M, q.s, q.xlo, x_bias);
             if (last) continue;
-            gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, Kln, 3 * D, q.s);
-            attention(m, q.a->qkv, q.a->y, q.n, q.s, false);
+            gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, Kln, ldq, q.s);
+            attention(m, q.a->qkv, q.a->y, q.n, q.s, false, ldq);
         }
         for (int p = 0; p < parts; ++p) {
             Part& q = pt[p];
@@ -591,22 +602,22 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
                     // row from the hi plane, and the CLS rows' hi-plane rows + statistics gathered for the query columns
                     PpFold f;
                     f.cvec = ly.cqkv + D; f.stats = q.a->stats;
-                    launch_pp<EPI_LNF>(m, q.a->x, (const char*)ly.wqkv_f + (size_t)D * D * 2, ly.bqkv_f + D, (char*)q.a->qkv + (size_t)D * 2, pad256(q.M), 2 * D, D, 3 * D, f, s);
+                    launch_pp<EPI_LNF>(m, q.a->x, (const char*)ly.wqkv_f + (size_t)D * D * 2, ly.bqkv_f + D, (char*)q.a->qkv + (size_t)D * 2, pad256(q.M), 2 * D, D, ldq, f, s);
                     hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, (const bf16_t*)q.a->x, (bf16_t*)q.a->c_y, (int)q.n, (size_t)S, D);
                     hipLaunchKernelGGL(gather_stats_kernel, dim3((unsigned)((q.n + 255) / 256)), dim3(256), 0, s, q.a->stats, q.a->c_stats, (int)q.n, (size_t)S);
                     PpFold fq;
                     fq.cvec = ly.cqkv; fq.stats = q.a->c_stats;
                     launch_pp<EPI_LNF>(m, q.a->c_y, ly.wqkv_f, ly.bqkv_f, q.a->c_ctx, pad256(q.n), D, D, D, fq, s);
                 } else {
-                gemm<EPI_BIAS>(m, q.a->y, (const char*)ly.wqkv + (size_t)D * Kln * es, ly.bqkv + D, (char*)q.a->qkv + (size_t)D * es, q.M, 2 * D, Kln, 3 * D, s);
+                gemm<EPI_BIAS>(m, q.a->y, (const char*)ly.wqkv + (size_t)D * Kln * es, ly.bqkv + D, (char*)q.a->qkv + (size_t)D * es, q.M, 2 * D, Kln, ldq, s);
                 if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_y, (int)q.n, (size_t)S, Kln);
                 else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb), dim3(256), 0, s, (const float*)q.a->y, (float*)q.a->c_y, (int)q.n, (size_t)S, D);
                 gemm<EPI_BIAS>(m, q.a->c_y, ly.wqkv, ly.bqkv, q.a->c_ctx, q.n, D, Kln, D, s);
                 }
-                if (deferred) hipLaunchKernelGGL((scatter_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, (const bf16_t*)q.a->c_ctx, (bf16_t*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)3 * D);
-                else hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3(gb), dim3(256), 0, s, (const float*)q.a->c_ctx, (float*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)3 * D);
+                if (deferred) hipLaunchKernelGGL((scatter_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, (const bf16_t*)q.a->c_ctx, (bf16_t*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)ldq);
+                else hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3(gb), dim3(256), 0, s, (const float*)q.a->c_ctx, (float*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)ldq);
                 HIP_CHECK(hipGetLastError());
-                attention(m, q.a->qkv, q.a->y, q.n, s, true);
+                attention(m, q.a->qkv, q.a->y, q.n, s, true, ldq);
                 const unsigned gb2 = gb;
                 if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb2), dim3(256), 0, s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_ctx, (int)q.n, (size_t)S, D);
                 else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb2), dim3(256), 0, s, (const float*)q.a->y, (float*)q.a->c_ctx, (int)q.n, (size_t)S, D);
@@ -889,6 +900,20 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         if (m->text) { m->order.sync(); drop_text_graph(m); }
         if (k == "full_last") m->full_last = value != 0;
         else if (k == "attn_shift") m->attn_shift = value != 0;
+        else if (k == "qkv_pad") {   // the activation sets are sized by it: rebuild on next use
+            if (value < 0 || value > 1024 || value % 64) fail(MI_ERR_INVALID, "qkv_pad must be a multiple of 64 in 0..1024");
+            if (m->text) fail(MI_ERR_INVALID, "the text tower's qkv rows are dense");
+            if (value != m->qkv_pad) {
+                m->order.sync();
+                for (void* p : m->ws) HIP_CHECK(hipFree(p));
+                m->ws.clear();
+                m->cap = 0;
+                m->qkv_pad = value;
+            }
+        } else if (k == "attn_order") {
+            if (value < 0 || value > 1) fail(MI_ERR_INVALID, "attn_order must be 0 or 1");
+            m->attn_order = value;
+        }
         else if (k == "split_tail") m->split_tail = value != 0;
         else if (k == "gemm_order") {
             if (value < 0 || value > 16) fail(MI_ERR_INVALID, "gemm_order must be 0..16");
@@ -918,7 +943,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, text_fuse, attn_f32_mfma, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, attn_order, qkv_pad, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, text_fuse, attn_f32_mfma, max_batch, parts)", key);
     });
 }
 
@@ -1342,11 +1367,23 @@ int mi_op_attention(int device, int precision, const float* qkv, float* ctx, siz
         m.precision = precision; m.S = s_tok; m.D = d; m.H = heads;
         if (const char* e = std::getenv("MI_OP_ATTN")) m.attn_ver = std::atoi(e) == 1 ? 1 : 2;   // test hook: which bf16 kernel
         if (const char* e = std::getenv("MI_OP_ATTN_SHIFT")) m.attn_shift = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MI_OP_ATTN_ORDER")) m.attn_order = std::atoi(e) != 0;   // test hook: first pair of a workgroup
         if (const char* e = std::getenv("MI_OP_ATTN_F32_MFMA")) m.attn_f32_mfma = std::atoi(e) != 0;   // test hook: 0 = the one-thread-per-query fp32 kernel
         const size_t rows = n_img * s_tok;
         void* dq = sc.up(precision, qkv, rows, 3 * (size_t)d, pad256(rows));
         void* dc = sc.bytes(pad256(rows) * d * 4);
-        attention(&m, dq, dc, n_img, nullptr);
+        int ldq = 3 * d;
+        if (const char* e = std::getenv("MI_OP_ATTN_QKV_PAD")) {   // test hook: the padded row pitch the tower gives q|k|v where attn32 runs
+            const int pad = std::atoi(e);
+            if (pad > 0 && attn32_applies(&m)) {
+                ldq = 3 * d + pad;
+                void* padded = sc.bytes(pad256(rows) * (size_t)ldq * 2);
+                HIP_CHECK(hipMemset(padded, 0xFF, pad256(rows) * (size_t)ldq * 2));   // NaN patterns between the rows: a stray read shows
+                HIP_CHECK(hipMemcpy2D(padded, (size_t)ldq * 2, dq, (size_t)3 * d * 2, (size_t)3 * d * 2, rows, hipMemcpyDeviceToDevice));
+                dq = padded;
+            }
+        }
+        attention(&m, dq, dc, n_img, nullptr, false, ldq);
         HIP_CHECK(hipDeviceSynchronize());
         sc.down(precision, dc, ctx, rows * d);
     });

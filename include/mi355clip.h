@@ -103,6 +103,12 @@ int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* nee
  *                the pooled output is the CLS row, the result is bit-identical either way)
  *   "attn_shift" 1 = always take the shifted (exact row maximum) pass of the bf16 attention (default 0: taken
  *                only for queries whose softmax numerators leave the exponent range; same result)
+ *   "attn_order" which (image, head) pairs a workgroup of the persistent bf16 attention walks: 1 (default) = the 32 workgroups
+ *                that share an XCD start on all 16 heads of two images; 0 = workgroup b starts at pair b (an XCD then sits on
+ *                two heads for the whole launch: a quarter of its L2 channels).  Same bits
+ *   "qkv_pad"    elements added to the row pitch of the bf16 image tower's q|k|v activations where the persistent attention
+ *                runs (default 128 = 256 bytes; a multiple of 64 in 0..1024; 0 = dense 3 D rows, the layout of rounds 1-4:
+ *                a head's pieces then fall on few memory channels and attention takes 15-20 % longer).  Same bits
  *   "split_tail" 0 = do not cut a short last round of GEMM tiles into quadrant tasks (A/B hook)
  *   "gemm_order" tile order of the persistent GEMM: np > 0 (default 4) = an XCD's concurrent tiles are a (32 / np) x np patch
  *                inside one column group of np weight tiles (which stay in its L2); 0 = row-major.  Same bits; -2.3 % per forward

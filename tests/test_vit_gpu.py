@@ -199,6 +199,24 @@ def test_attention32_forced_shift_and_old_kernel_agree(built, monkeypatch):
     assert np.abs(old - base).max() <= 8e-3 * scale         # the 16-query-tile kernel (q rounded before its scale)
 
 
+@pytest.mark.parametrize("S,n,H", [(257, 20, 16), (197, 5, 12), (100, 3, 2), (257, 1, 16)])
+def test_attention32_row_pitch_and_pair_order_do_not_change_a_bit(built, monkeypatch, S, n, H):
+    """The tower pads the rows of q|k|v (a head's 128-byte pieces then spread over the memory channels) and starts the
+    32 workgroups that share an XCD on different heads.  Both are layouts / orders: the kernel on padded rows (NaN patterns
+    between them) and with either start order returns the bits of the dense, plain-order run — persistent grid (n * H >
+    256 pairs), short grids and one image."""
+    rng = np.random.default_rng(40 + S)
+    qkv = rng.standard_normal((n, S, 3 * 64 * H)).astype(np.float32)
+    monkeypatch.setenv("MI_OP_ATTN_ORDER", "0")
+    base = ops.attention(qkv, H, PRECISION_BF16)
+    assert np.isfinite(base).all()
+    for pad, order in ((0, 1), (64, 0), (128, 1), (192, 1), (1024, 0)):
+        monkeypatch.setenv("MI_OP_ATTN_QKV_PAD", str(pad))
+        monkeypatch.setenv("MI_OP_ATTN_ORDER", str(order))
+        got = ops.attention(qkv, H, PRECISION_BF16)
+        assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), (pad, order)
+
+
 @pytest.mark.parametrize("prec,tol", [(PRECISION_F32, 2e-6), (PRECISION_BF16, 5e-3)])
 @pytest.mark.parametrize("D", [128, 768, 1024])
 def test_layernorm(built, prec, tol, D):
@@ -512,6 +530,24 @@ def test_ab_hooks_of_the_bf16_tower_do_not_change_a_bit(l14, ln_fold):
         m.set_option("ln_nt", nt)
         m.set_option("gemm_order", order)   # the persistent GEMM's tile order (0 = row-major, default 4)
         assert np.array_equal(m.forward(px).view(np.uint32), ref.view(np.uint32)), (rows_, nt, order)
+    # the row pitch of q|k|v (padded by default so that a head's pieces spread over the memory channels; 0 = the dense
+    # rows of rounds 1-4) and the pair a workgroup of the persistent attention starts on: layouts and orders, not arithmetic.
+    # 40 and 41 images: whole and ragged halves; a grow-and-shrink sequence of the pitch on ONE handle (it re-sizes the
+    # activation sets); the CLS-only last layer scatters its query rows into the padded rows as well
+    px41 = synth.preprocess_rgb8(synth.images_u8(79, 41, cfg.image))
+    ref41 = m.forward(px41)
+    for pad, order in ((0, 0), (192, 1), (64, 0), (0, 1), (1024, 1), (128, 1)):
+        m.set_option("qkv_pad", pad)
+        m.set_option("attn_order", order)
+        assert np.array_equal(m.forward(px).view(np.uint32), ref.view(np.uint32)), (pad, order)
+        assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32)), (pad, order)
+    m.set_option("full_last", 1)
+    m.set_option("qkv_pad", 64)
+    assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32))
+    with pytest.raises(Exception):
+        m.set_option("qkv_pad", 32)    # 128-byte row segments of the GEMM epilogue: multiples of 64 elements only
+    with pytest.raises(Exception):
+        m.set_option("attn_order", 2)
     m.close()
 
 

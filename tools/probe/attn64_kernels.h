@@ -29,6 +29,9 @@
 //     there is one vector-memory instruction per 5 MFMAs (a long-sequence flash kernel has one per 16), and what they
 //     cost the computing wave is not only their issue.
 #pragma once
+#ifndef ATTN32_ABL
+#define ATTN32_ABL 0   // ablation mask of rounds 2-3 (one cost removed at a time); 0 = the kernel as it was measured
+#endif
 #include "../../image_search_amd/csrc/attn32_kernels.h"
 
 namespace mi {

@@ -46,14 +46,14 @@ int main(int argc, char** argv) {
         const int pairs = n * H, grid = pairs < 256 ? pairs : 256;
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         for (int shift = 0; shift < 2; ++shift) {
-            const float us = time_us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 0, shift); }, 20);
+            const float us = time_us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 0, shift, 1, 3 * D, D); }, 20);
             printf("attn32<288,257> shift=%d n=%d: %.1f us per launch  (%.0f TFLOP/s, %.2f TB/s of q,k,v,ctx)\n", shift, n, us,
                    4.0 * S * S * 64 * H * n / us * 1e-6, (double)M * 4 * D * 2 / us * 1e-6);
         }
 #ifdef ATTN32_STAMPS
         {
             CK(hipMemset(d_st, 0, 256 * 8 * 8 * 8));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 0, 0);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 0, 0, 1, 3 * D, D);
             CK(hipDeviceSynchronize());
             static unsigned long long h[256 * 8 * 8];
             CK(hipMemcpy(h, d_st, sizeof h, hipMemcpyDeviceToHost));
@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
             }
         }
 #endif
-        const float us1 = time_us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 1, 0); }, 20);
+        const float us1 = time_us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 1, 0, 1, 3 * D, D); }, 20);
         printf("attn32<288,257> first tile only (last layer): %.1f us\n", us1);
     }
     {

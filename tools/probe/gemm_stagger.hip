@@ -86,6 +86,7 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         std::vector<unsigned long long> b(256);
         CK(hipMemcpyFromSymbol(b.data(), HIP_SYMBOL(pp_busy), 256 * 8));
+        if (getenv("PP_XCD")) { printf("   busy us by blockIdx %% 8:"); for (int x = 0; x < 8; ++x) { double a = 0; for (int i = x; i < 256; i += 8) a += b[i] / 100.0; printf(" %.1f", a / 32); } printf("\n"); }
         std::sort(b.begin(), b.end());
         *busy_med = b[128] / 100.0; *busy_max = b[255] / 100.0;
         return (double)ms / reps * 1e3;
