@@ -465,6 +465,12 @@ def test_one_text_query_takes_the_skinny_gemm_path_within_the_same_bound(built, 
     assert np.array_equal(m.embed(big)[:ids.shape[0]], batched)
     for _ in range(4):
         assert np.array_equal(m.embed(ids[:1]), first)             # a fresh eager / capture / replay cycle on the new buffers
+    # options that re-size the IMAGE tower's activation sets are refused on a text handle (its workspace is another one:
+    # freeing m->ws under it would leave the text buffers dangling), and refusing leaves the handle usable
+    for key, value in (("qkv_pad", 64), ("parts", 1)):
+        with pytest.raises(Exception):
+            m.set_option(key, value)
+    assert np.array_equal(m.embed(ids[:1]), first)
     m.close()
 
 
