@@ -12,9 +12,17 @@
 #include "../../image_search_amd/csrc/vit_kernels.h"
 __device__ unsigned long long attn_clk[256 * 2];
 #define ATTN32_STAMP
+#ifdef CLK_SEGMENTS   // also the five segments of an iteration, per wave (as attn_stamps.h): 0 own loads landed, 1 barrier, 2 issue next, 3 whole tile, 4 split tile
+__device__ unsigned long long attn_seg[256 * 8 * 8];
+#define ATTN32_STAMP_BEGIN const unsigned long long c0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime(); unsigned long long acc_[5] = {0, 0, 0, 0, 0}, last_ = c0_;
+#define ATTN32_STAMP(SLOT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_[SLOT] += now_ - last_; last_ = __builtin_amdgcn_s_memtime(); }
+#define ATTN32_STAMP_END if (threadIdx.x == 0) { attn_clk[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - c0_; attn_clk[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0_; } \
+    if (lane == 0) for (int j = 0; j < 5; ++j) attn_seg[((size_t)blockIdx.x * 8 + wave) * 8 + j] = acc_[j];
+#else
 #define ATTN32_STAMP_BEGIN const unsigned long long c0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime();
 #define ATTN32_STAMP(SLOT)
 #define ATTN32_STAMP_END if (threadIdx.x == 0) { attn_clk[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - c0_; attn_clk[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0_; }
+#endif
 #include "../../image_search_amd/csrc/attn32_kernels.h"
 using namespace mi;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -53,6 +61,19 @@ int main(int argc, char** argv) {
         if (order == 1) { printf("by head (slot %% 16):"); for (int hh = 0; hh < 16; ++hh) { double a = 0; int k = 0; for (int b = 0; b < grid; ++b) if ((b >> 3) % 16 == hh) { a += c[2 * b + 1] / 100.0; ++k; } printf(" %.0f", a / k); } printf("\n"); }
         for (int b = 0; b < grid; ++b) printf("%d:%.0f%s", b, c[2 * b + 1] / 100.0, (b % 16 == 15) ? "\n" : " ");
     }
+#ifdef CLK_SEGMENTS
+    {
+        std::vector<unsigned long long> sg(256 * 8 * 8);
+        CK(hipMemcpyFromSymbol(sg.data(), HIP_SYMBOL(attn_seg), sg.size() * 8));
+        const char* nm[5] = {"own loads landed", "barrier", "issue next", "whole tile", "split tile"};
+        for (int w = 0; w < 8; ++w) {
+            printf("wave %d, mean shader cycles per pair:", w);
+            double tot = 0;
+            for (int j = 0; j < 5; ++j) { double a = 0; for (int b = 0; b < grid; ++b) a += (double)sg[((size_t)b * 8 + w) * 8 + j]; a /= grid * ((double)pairs / grid); tot += a; printf("  %s %.0f", nm[j], a); }
+            printf("  | sum %.0f\n", tot);
+        }
+    }
+#endif
     std::vector<double> ghz, busy, cyc;
     for (int b = 0; b < grid; ++b) { ghz.push_back(c[2 * b] / (double)c[2 * b + 1] * 0.1); busy.push_back(c[2 * b + 1] / 100.0); cyc.push_back((double)c[2 * b]); }
     std::sort(ghz.begin(), ghz.end()); std::sort(busy.begin(), busy.end()); std::sort(cyc.begin(), cyc.end());
