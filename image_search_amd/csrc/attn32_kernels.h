@@ -561,9 +561,9 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
 
     // The first pair of workgroup b (it then walks first, first + G, ...).  Blocks b, b + 8, ... share an XCD (round-robin
     // dispatch, tools/probe/xcc_probe.hip), and with first = b every one of an XCD's 32 workgroups sits on the two heads
-    // b % 8 and b % 8 + 8 for the whole launch: K / V rows 6 144 bytes apart at two fixed column offsets, i.e. a quarter of
-    // that XCD's L2 channels — measured: the workgroups of one slot (b % 8 == 3 on every box) took 25 % more cycles than
-    // the rest and the launch waited for them.  pair_order 1 transposes the start: slot s of XCD x begins at pair
+    // b % 8 and b % 8 + 8 for the whole launch.  On dense qkv rows the heads 3 and 11 cost 25 % more cycles than the others
+    // (measured per workgroup, tools/probe/attn_clock.hip), so one XCD slot ran a quarter behind and the launch waited for
+    // it; the padded row pitch removes most of that, and pair_order 1 transposes the start: slot s of XCD x begins at pair
     // x * G / 8 + s, so the workgroups that share an L2 work on all 16 heads of two images at any one time.
     const int first = (pair_order == 1 && (G & 7) == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     int pair = first;
