@@ -472,7 +472,8 @@ __host__ __device__ constexpr int attn32_lds_bytes(int s_pad) { return 2 * (2 * 
 template <int S_PAD, int S_CT, bool PRESCALED>
 __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int S_rt,
                                                              int D, int H, int n_pairs, int cls_only, int force_shift,
-                                                             int pair_order, int ld_qkv, int ld_ctx) {
+                                                             int pair_order, int ld_qkv, int ld_ctx, uint32_t head_stride,
+                                                             uint32_t sel_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int IMG = 2 * S_PAD * 128;  // K then V
     constexpr int NPIECE = S_PAD / 8;     // 1-KiB DMA pieces per matrix
@@ -484,7 +485,15 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
     // row pitches in elements: qkv rows may be padded beyond 3 D, ctx rows beyond D.  Dense qkv rows (6 144 bytes at
     // D = 1024) put the 128-byte K / V / q pieces of a head on few memory channels: the kernel ran 15-20 % longer, and a
     // quarter longer still on the heads 3 and 11 (tools/probe/attn_clock.hip; mi_clip pads the tower's qkv rows)
+    // Where a head's q, K and V lie (elements): row t of image i, head hh of selector sel (0 = q, 1 = k, 2 = v) starts at
+    //   qkv + (i * S + t) * ld_qkv + hh * head_stride + sel * sel_stride.
+    // Token rows [M][3 D (+ pad)]: head_stride = 64, sel_stride = D.  Head-major planes [3][H][Mp][64] (what the q/k/v GEMM
+    // of the tower writes under option "qkv_layout" = 1): ld_qkv = 64, head_stride = Mp * 64, sel_stride = H * Mp * 64 — a
+    // head's K (V, q) of one image is then ONE contiguous block of S * 128 bytes and every DMA piece one contiguous KiB.
     const size_t ld = (size_t)ld_qkv, ldc = (size_t)ld_ctx;
+    // K and V get a descriptor each, S rows long from the pair's first K / V row: rows >= S arrive as zeros in either layout
+    // (in the head-major one the next image's rows lie right behind, and 0 * Inf of a foreign row must not reach this one)
+    const uint32_t kv_bytes = (uint32_t)((size_t)(S - 1) * ld * 2 + 128);
     const int r = lane & 31, h = lane >> 5;
     const int G = gridDim.x;
 
@@ -500,13 +509,12 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
     const uint32_t voff0 = (uint32_t)rr * (uint32_t)(ld * 2) + 16u * (uint32_t)(cp ^ swz32(rr));
     const uint32_t voff1 = (uint32_t)rr * (uint32_t)(ld * 2) + 16u * (uint32_t)(cp ^ swz32(8 + rr));
     // (image, head) of a pair, as scalars: one division per iteration
-    struct Pair { const bf16_t* base; bf16_t* ctx_b; uint32_t bytes; };
+    struct Pair { const bf16_t* base; bf16_t* ctx_b; };
     auto pair_of = [&](int pr) {
         const int img = __builtin_amdgcn_readfirstlane(pr / H), hh = __builtin_amdgcn_readfirstlane(pr - img * H);
         Pair q;
-        q.base = qkv + (size_t)img * S * ld + hh * 64;
+        q.base = qkv + (size_t)img * S * ld + (size_t)hh * head_stride;
         q.ctx_b = ctx + (size_t)img * S * ldc + hh * 64;
-        q.bytes = (uint32_t)((size_t)S * ld * 2 - (size_t)hh * 128);
         return q;
     };
     // one 1-KiB piece of K and of V: HBM -> LDS by LDS-DMA (8 rows per wave-instruction, swizzle on the source chunk);
@@ -518,13 +526,14 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         const bf16_t* base = reinterpret_cast<const bf16_t*>(
             ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32)) << 32) |
             (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bp));
-        const rsrc_t kvr = make_rsrc(base, (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.bytes));
+        const rsrc_t kr = make_rsrc(base + sel_stride, kv_bytes);
+        const rsrc_t vr = make_rsrc(base + 2 * (size_t)sel_stride, kv_bytes);
         unsigned char* Kd = smem + b * IMG;
         unsigned char* Vd = Kd + S_PAD * 128;
         const uint32_t so = (uint32_t)(8 * j) * (uint32_t)(ld * 2);
         const uint32_t vo = (j & 1) ? voff1 : voff0;
-        glds16_buf(kvr, vo, so + (uint32_t)D * 2u, Kd + j * 1024);
-        glds16_buf(kvr, vo, so + (uint32_t)D * 4u, Vd + j * 1024);
+        glds16_buf(kr, vo, so, Kd + j * 1024);
+        glds16_buf(vr, vo, so, Vd + j * 1024);
     };
     auto load_q_raw = [&](bf16x8 (&q)[4], const Pair& pr, int qrow) {
 #pragma unroll

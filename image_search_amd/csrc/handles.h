@@ -86,6 +86,7 @@ struct mi_clip {
     bool q_prescaled = false; // log2(e)/8 folded into W_q / b_q at load (attn_ver 2 in the tower)
     bool attn_shift = false;  // force the shifted (exact maximum) pass of attn32 — test hook
     int qkv_pad = 128;        // elements added to the image tower's qkv row pitch where attn32 runs (vit.hip: qkv_pitch)
+    int qkv_layout = 0;       // 0 = token rows [M][3D + pad]; 1 = head-major planes [3][H][Mp][64] (vit.hip: qkv_head_major)
     int attn_order = 1;       // attn32: first pair of workgroup b (0 = b; 1 = transposed, an XCD's workgroups spread over all heads)
     bool full_last = false;   // compute the dead rows of the last layer too (A/B against the reference graph)
     bool split_tail = true;   // cut a short last round of GEMM tiles into quadrant tasks

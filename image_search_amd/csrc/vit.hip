@@ -45,6 +45,12 @@ bool attn32_applies(const mi_clip* m) {
     return m->precision != MI_PRECISION_F32 && m->attn_ver >= 2 && !m->text && m->S > 64 && m->S <= 288;
 }
 size_t qkv_pitch(const mi_clip* m) { return (size_t)3 * m->D + (attn32_applies(m) ? (size_t)m->qkv_pad : 0); }
+// Option "qkv_layout" = 1: q|k|v as head-major planes [3][H][Mp][64] instead of token rows — the persistent GEMM's epilogue
+// writes one contiguous KiB per store (PpFold::col_stride) and attn32 fetches a head's K / V / q as contiguous blocks.
+// Same values at other addresses: the forward is bit-identical.  The buffer (sized for the padded rows) holds either.
+bool qkv_head_major(const mi_clip* m) {
+    return m->qkv_layout == 1 && attn32_applies(m) && m->precision == MI_PRECISION_BF16 && !m->split_ln && m->D % 256 == 0;
+}
 
 
 template <typename T>
@@ -353,16 +359,20 @@ void launch_pp(mi_clip* m, const void* X, const void* W, const float* bias, void
 }
 
 // bf16 GEMM with bf16 output: the persistent 256x256 kernel when the shape allows, else 128x128
+// col_stride != 64: head-major output planes (PpFold::col_stride, ldo = 64) — the persistent kernel only
 template <int EPI>
 void gemm(mi_clip* m, const void* X, const void* W, const float* bias, void* out, size_t Mrows, int N, int K, int ldo,
-          hipStream_t s) {
+          hipStream_t s, uint32_t col_stride = 64) {
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) {
         const size_t Mp = pad256(Mrows);
-        if (m->precision == MI_PRECISION_BF16 && pp_shape_ok(Mp, N, K, ldo)) {
-            launch_pp<EPI>(m, X, W, bias, out, Mp, N, K, ldo, PpFold(), s);
+        if (m->precision == MI_PRECISION_BF16 && pp_shape_ok(Mp, N, K, col_stride == 64 ? ldo : N)) {
+            PpFold f;
+            f.col_stride = col_stride;
+            launch_pp<EPI>(m, X, W, bias, out, Mp, N, K, ldo, f, s);
             return;
         }
     }
+    if (col_stride != 64) fail(MI_ERR_INVALID, "head-major output needs the persistent GEMM");
     gemm_p<EPI>(m->precision, X, W, bias, out, Mrows, N, K, ldo, s);
 }
 
@@ -398,8 +408,17 @@ void layer_norm(mi_clip* m, float* x, const bf16_t* d1, const bf16_t* d2, bool w
 }
 
 // first_tile_only: only the leading query tile / block of every (image, head) -- it holds the CLS row
-void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, bool first_tile_only = false, int ld_qkv = 0) {
+// hm_rows > 0: qkv lies head-major, [3][H][hm_rows][64] (attn32 only; the q/k/v GEMM wrote it so, option "qkv_layout")
+void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, bool first_tile_only = false, int ld_qkv = 0,
+               size_t hm_rows = 0) {
     if (ld_qkv == 0) ld_qkv = 3 * m->D;
+    uint32_t head_stride = 64, sel_stride = (uint32_t)m->D;
+    if (hm_rows) {
+        if (!attn32_applies(m)) fail(MI_ERR_INVALID, "head-major q|k|v is the attn32 kernel's layout");
+        ld_qkv = 64;
+        head_stride = (uint32_t)(hm_rows * 64);
+        sel_stride = (uint32_t)((size_t)m->H * hm_rows * 64);
+    }
     if (m->precision == MI_PRECISION_F32) {
         if (m->S <= 272 && m->attn_f32_mfma) {   // on the matrix pipe (exact-f32 MFMA), one workgroup per (image, head)
 #define MI_ATTNF(SP)                                                                                                    \
@@ -425,10 +444,10 @@ void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, 
         const int pairs = (int)(n * m->H), grid = std::min(pairs, m->n_cu);                                            \
         if (m->q_prescaled) {                                                                                          \
             allow_lds_once(once[1], attn32_bf16_kernel<SP, SC, true>, LDS);                                            \
-            hipLaunchKernelGGL((attn32_bf16_kernel<SP, SC, true>), dim3(grid), dim3(512), LDS, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, pairs, first_tile_only ? 1 : 0, m->attn_shift ? 1 : 0, m->attn_order, ld_qkv, m->D); \
+            hipLaunchKernelGGL((attn32_bf16_kernel<SP, SC, true>), dim3(grid), dim3(512), LDS, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, pairs, first_tile_only ? 1 : 0, m->attn_shift ? 1 : 0, m->attn_order, ld_qkv, m->D, head_stride, sel_stride); \
         } else {                                                                                                       \
             allow_lds_once(once[0], attn32_bf16_kernel<SP, SC, false>, LDS);                                           \
-            hipLaunchKernelGGL((attn32_bf16_kernel<SP, SC, false>), dim3(grid), dim3(512), LDS, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, pairs, first_tile_only ? 1 : 0, m->attn_shift ? 1 : 0, m->attn_order, ld_qkv, m->D); \
+            hipLaunchKernelGGL((attn32_bf16_kernel<SP, SC, false>), dim3(grid), dim3(512), LDS, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, pairs, first_tile_only ? 1 : 0, m->attn_shift ? 1 : 0, m->attn_order, ld_qkv, m->D, head_stride, sel_stride); \
         }                                                                                                              \
     }
         if (m->S == 257) MI_ATTN32(288, 257)       // ViT-L/14, ViT-H/14 @224
@@ -552,6 +571,11 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     const bool full_last = m->full_last;
     const int nb = D / 32;
     const int ldq = (int)qkv_pitch(m);   // row pitch of qkv (padded where attn32 runs)
+    // head-major q|k|v (option "qkv_layout"): per part, planes of its padded row count
+    const bool hm = qkv_head_major(m) && pp_shape_ok(pad256((n / parts + 1) * (size_t)S), 3 * D, D, 3 * D);
+    auto hm_rows = [&](const Part& q) { return hm ? pad256(q.M) : (size_t)0; };
+    auto qkv_cs = [&](const Part& q) { return hm ? (uint32_t)(pad256(q.M) * 64) : 64u; };
+    const int ldq_o = hm ? 64 : ldq;   // the q/k/v GEMM's output row pitch
     auto ln_stats = [&](Part& q) {   // the partial sums of the GEMM just enqueued -> {rstd, -mean rstd} per (padded) row
         const size_t Mp = pad256(q.M);
         hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(Mp / 16)), dim3(256), 0, q.s, q.a->part, q.a->stats, (int)Mp, nb, 1.0f / (float)D, m->eps);
@@ -567,15 +591,15 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
             if (fold && last) continue;   // LN1 folded into the K / V and CLS-query GEMMs below
             if (fold) {   // every layer's LN1 is folded, the last one's too (its LN2 is not: it runs on the CLS rows)
                 PpFold f;
-                f.cvec = ly.cqkv; f.stats = q.a->stats;
-                launch_pp<EPI_LNF>(m, q.a->x, ly.wqkv_f, ly.bqkv_f, q.a->qkv, pad256(q.M), 3 * D, D, ldq, f, q.s);
-                attention(m, q.a->qkv, q.a->y, q.n, q.s, false, ldq);
+                f.cvec = ly.cqkv; f.stats = q.a->stats; f.col_stride = qkv_cs(q);
+                launch_pp<EPI_LNF>(m, q.a->x, ly.wqkv_f, ly.bqkv_f, q.a->qkv, pad256(q.M), 3 * D, D, ldq_o, f, q.s);
+                attention(m, q.a->qkv, q.a->y, q.n, q.s, false, ldq, hm_rows(q));
                 continue;
             }
             layer_norm_x(m, q.a->x, q.p1, q.p2, true, q.a->y, ly.ln1w, ly.ln1b, q.M, q.s, q.xlo, x_bias);
             if (last) continue;
-            gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, Kln, ldq, q.s);
-            attention(m, q.a->qkv, q.a->y, q.n, q.s, false, ldq);
+            gemm<EPI_BIAS>(m, q.a->y, ly.wqkv, ly.bqkv, q.a->qkv, q.M, 3 * D, Kln, ldq_o, q.s, qkv_cs(q));
+            attention(m, q.a->qkv, q.a->y, q.n, q.s, false, ldq, hm_rows(q));
         }
         for (int p = 0; p < parts; ++p) {
             Part& q = pt[p];
@@ -597,27 +621,29 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
                 // leading query tile keep whatever the buffer held: their context rows are never read)
                 const size_t es = esize(m);
                 const unsigned gb = (unsigned)std::min<size_t>((q.n * (size_t)D / 4 + 255) / 256, 4096);
+                // the K | V columns start D elements into a token row, or at plane H of the head-major form
+                char* kv_out = (char*)q.a->qkv + (hm ? (size_t)m->H * pad256(q.M) * 64 : (size_t)D) * es;
                 if (fold) {
                     // the same EPI_LNF arithmetic as the full layer's q/k/v launch, so the same bits: K | V columns of every
                     // row from the hi plane, and the CLS rows' hi-plane rows + statistics gathered for the query columns
                     PpFold f;
-                    f.cvec = ly.cqkv + D; f.stats = q.a->stats;
-                    launch_pp<EPI_LNF>(m, q.a->x, (const char*)ly.wqkv_f + (size_t)D * D * 2, ly.bqkv_f + D, (char*)q.a->qkv + (size_t)D * 2, pad256(q.M), 2 * D, D, ldq, f, s);
+                    f.cvec = ly.cqkv + D; f.stats = q.a->stats; f.col_stride = qkv_cs(q);
+                    launch_pp<EPI_LNF>(m, q.a->x, (const char*)ly.wqkv_f + (size_t)D * D * 2, ly.bqkv_f + D, kv_out, pad256(q.M), 2 * D, D, ldq_o, f, s);
                     hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, (const bf16_t*)q.a->x, (bf16_t*)q.a->c_y, (int)q.n, (size_t)S, D);
                     hipLaunchKernelGGL(gather_stats_kernel, dim3((unsigned)((q.n + 255) / 256)), dim3(256), 0, s, q.a->stats, q.a->c_stats, (int)q.n, (size_t)S);
                     PpFold fq;
                     fq.cvec = ly.cqkv; fq.stats = q.a->c_stats;
                     launch_pp<EPI_LNF>(m, q.a->c_y, ly.wqkv_f, ly.bqkv_f, q.a->c_ctx, pad256(q.n), D, D, D, fq, s);
                 } else {
-                gemm<EPI_BIAS>(m, q.a->y, (const char*)ly.wqkv + (size_t)D * Kln * es, ly.bqkv + D, (char*)q.a->qkv + (size_t)D * es, q.M, 2 * D, Kln, ldq, s);
+                gemm<EPI_BIAS>(m, q.a->y, (const char*)ly.wqkv + (size_t)D * Kln * es, ly.bqkv + D, kv_out, q.M, 2 * D, Kln, ldq_o, s, qkv_cs(q));
                 if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_y, (int)q.n, (size_t)S, Kln);
                 else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb), dim3(256), 0, s, (const float*)q.a->y, (float*)q.a->c_y, (int)q.n, (size_t)S, D);
                 gemm<EPI_BIAS>(m, q.a->c_y, ly.wqkv, ly.bqkv, q.a->c_ctx, q.n, D, Kln, D, s);
                 }
-                if (deferred) hipLaunchKernelGGL((scatter_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, (const bf16_t*)q.a->c_ctx, (bf16_t*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)ldq);
-                else hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3(gb), dim3(256), 0, s, (const float*)q.a->c_ctx, (float*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)ldq);
+                if (deferred) hipLaunchKernelGGL((scatter_rows_kernel<bf16_t>), dim3(gb), dim3(256), 0, s, (const bf16_t*)q.a->c_ctx, (bf16_t*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)ldq_o, (size_t)qkv_cs(q));
+                else hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3(gb), dim3(256), 0, s, (const float*)q.a->c_ctx, (float*)q.a->qkv, (int)q.n, (size_t)S, D, (size_t)ldq, (size_t)64);
                 HIP_CHECK(hipGetLastError());
-                attention(m, q.a->qkv, q.a->y, q.n, s, true, ldq);
+                attention(m, q.a->qkv, q.a->y, q.n, s, true, ldq, hm_rows(q));
                 const unsigned gb2 = gb;
                 if (deferred) hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(gb2), dim3(256), 0, s, (const bf16_t*)q.a->y, (bf16_t*)q.a->c_ctx, (int)q.n, (size_t)S, D);
                 else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gb2), dim3(256), 0, s, (const float*)q.a->y, (float*)q.a->c_ctx, (int)q.n, (size_t)S, D);
@@ -910,6 +936,10 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->qkv_pad = value;
             }
+        } else if (k == "qkv_layout") {   // takes effect with the next forward (every forward rewrites q|k|v)
+            if (value < 0 || value > 1) fail(MI_ERR_INVALID, "qkv_layout must be 0 (token rows) or 1 (head-major planes)");
+            if (m->text) fail(MI_ERR_INVALID, "the text tower's qkv rows are dense");
+            m->qkv_layout = value;
         } else if (k == "attn_order") {
             if (value < 0 || value > 1) fail(MI_ERR_INVALID, "attn_order must be 0 or 1");
             m->attn_order = value;
@@ -943,7 +973,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, attn_order, qkv_pad, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, text_fuse, attn_f32_mfma, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, attn_order, qkv_pad, qkv_layout, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, text_fuse, attn_f32_mfma, max_batch, parts)", key);
     });
 }
 
@@ -973,6 +1003,7 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         if (const char* e = std::getenv("MI_CLIP_IM2COL")) m->im2col_rows = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_CLIP_LN_NT")) m->ln_nt = std::atoi(e) & 3;
         if (const char* e = std::getenv("MI_CLIP_X24")) m->x24 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MI_CLIP_QKV_LAYOUT")) m->qkv_layout = std::atoi(e) == 1 ? 1 : 0;
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         m->n_cu = prop.multiProcessorCount;
@@ -1383,7 +1414,21 @@ int mi_op_attention(int device, int precision, const float* qkv, float* ctx, siz
                 dq = padded;
             }
         }
-        attention(&m, dq, dc, n_img, nullptr, false, ldq);
+        size_t hm_rows = 0;
+        if (const char* e = std::getenv("MI_OP_ATTN_LAYOUT")) {   // test hook: 1 = head-major planes [3][H][Mp][64] (option "qkv_layout")
+            if (std::atoi(e) == 1 && attn32_applies(&m)) {
+                hm_rows = pad256(rows);
+                std::vector<uint16_t> planes((size_t)3 * heads * hm_rows * 64, 0xFFFFu);   // NaN patterns in the padding rows
+                for (size_t r = 0; r < rows; ++r)
+                    for (size_t c = 0; c < 3 * (size_t)d; ++c) {
+                        const size_t sel = c / d, hh = (c % d) / 64, el = c % 64;
+                        planes[((sel * heads + hh) * hm_rows + r) * 64 + el] = f32_to_bf16_host(qkv[r * 3 * (size_t)d + c]);
+                    }
+                dq = sc.bytes(planes.size() * 2);
+                HIP_CHECK(hipMemcpy(dq, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+            }
+        }
+        attention(&m, dq, dc, n_img, nullptr, false, ldq, hm_rows);
         HIP_CHECK(hipDeviceSynchronize());
         sc.down(precision, dc, ctx, rows * d);
     });

@@ -48,6 +48,10 @@ struct PpFold {
     const float* stats = nullptr;  // EPI_LNF*: [M][2] = {rstd, -mean * rstd} of the rows of X (ln_stats_kernel / embed_ln_kernel)
     uint8_t* xlo = nullptr;        // EPI_RESID24: lo plane [M][ldo] of the residual stream (its hi plane is `out`)
     float* part = nullptr;         // EPI_RESID24: [M][N / 32][2] = {sum, sum of squares} of the new x over each 32-column block
+    // Elements between the starts of consecutive 64-column groups of one row of `out`.  64: token rows [M][ldo].
+    // M * 64 with ldo = 64: head-major planes [N / 64][M][64] — a wave's 64 columns are one plane and the 8 rows x 128 bytes of
+    // one of its stores are ONE contiguous KiB; the layout attn32_bf16_kernel streams (option "qkv_layout"; not with EPI_RESID24)
+    uint32_t col_stride = 64;
 };
 
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
@@ -479,12 +483,14 @@ __global__ void gather_stats_kernel(const float* __restrict__ stats, float* __re
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) *reinterpret_cast<v2f*>(dst + (size_t)i * 2) = *reinterpret_cast<const v2f*>(stats + (size_t)i * stride_rows * 2);
 }
+// cs: elements between consecutive 64-column groups of a dst row (64: plain rows; PpFold::col_stride for head-major planes)
 template <typename T>
-__global__ void scatter_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, size_t stride_rows, int D, size_t ld) {
+__global__ void scatter_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, size_t stride_rows, int D, size_t ld,
+                                    size_t cs = 64) {
     const int per = D * (int)sizeof(T) / 16;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n * per; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t r = i / per, c = i % per;
-        reinterpret_cast<v4u*>(dst + r * stride_rows * ld)[c] = reinterpret_cast<const v4u*>(src + r * D)[c];
+        const size_t r = i / per, c = i % per, col = c * (16 / sizeof(T));
+        *reinterpret_cast<v4u*>(dst + r * stride_rows * ld + (col >> 6) * cs + (col & 63)) = reinterpret_cast<const v4u*>(src + r * D)[c];
     }
 }
 
@@ -1195,7 +1201,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
     const uint32_t Kb = (uint32_t)K * 2;
     const rsrc_t xr = make_rsrc(X, (uint32_t)M * Kb);
     const rsrc_t wr = make_rsrc(W, (uint32_t)N * Kb);
-    const rsrc_t orr = make_rsrc(out, (uint32_t)M * (uint32_t)ldo * (uint32_t)sizeof(TO));
+    const uint32_t cs = fold.col_stride;
+    const rsrc_t orr = make_rsrc(out, cs == 64u ? (uint32_t)M * (uint32_t)ldo * (uint32_t)sizeof(TO) : (uint32_t)(N / 64) * cs * (uint32_t)sizeof(TO));
     const rsrc_t br = make_rsrc(bias, (uint32_t)N * 4u);
     const int rr = lane >> 3, p = lane & 7;
     const uint32_t x_lane = (uint32_t)rr * Kb + 16 * (p ^ rr);
@@ -1287,7 +1294,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
         if (a.kt + 1 < nk) { Pos q = a; q.kt = a.kt + 1; return q; }
         return pos_of_tile(a.tile + G);
     };
-    const uint32_t o_lane = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
+    const uint32_t o_lane = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)ldo + (uint32_t)wn * cs + (uint32_t)(8 * (lane & 7))) * 2u;
     unsigned char* patch = smem + 131072 + wave * 2304;
     // EPI_RESID24: the residual planes are updated in place (hi = `out`, bf16 pitch ldo; lo = fold.xlo, byte pitch ldo)
     const rsrc_t lor = make_rsrc(RES ? (const void*)fold.xlo : (const void*)out, RES ? (uint32_t)M * (uint32_t)ldo : 0u);
@@ -1305,7 +1312,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
     // bias (or the folded LayerNorm) + activation + bf16 + 128-byte row segments through the wave's LDS patch; clears acc
     auto epilogue = [&](int tm, int tn) {
         __builtin_amdgcn_sched_barrier(0);
-        const uint32_t o_tile = ((uint32_t)tm * 256u * (uint32_t)ldo + (uint32_t)tn * 256u) * 2u;
+        const uint32_t o_tile = ((uint32_t)tm * 256u * (uint32_t)ldo + (uint32_t)tn * 4u * cs) * 2u;
         v4f bv[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) bv[ni] = *reinterpret_cast<const v4f*>(bias_lds + (ni * 16 + 4 * g) * 4);
@@ -1510,8 +1517,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) cq[ni] = *reinterpret_cast<const v4f*>(bias_lds + 256 + (32 * nh + ni * 16 + 4 * g) * 4);
         }
-        const uint32_t q_tile = ((uint32_t)ttm * 256u * (uint32_t)ldo + (uint32_t)(ttn * 256)) * 2u;
-        const uint32_t q_lane = ((uint32_t)(wm * 128 + 64 * mh + (lane >> 2)) * (uint32_t)ldo + (uint32_t)(wn * 64 + 32 * nh + 8 * (lane & 3))) * 2u;
+        const uint32_t q_tile = ((uint32_t)ttm * 256u * (uint32_t)ldo + (uint32_t)ttn * 4u * cs) * 2u;
+        const uint32_t q_lane = ((uint32_t)(wm * 128 + 64 * mh + (lane >> 2)) * (uint32_t)ldo + (uint32_t)wn * cs + (uint32_t)(32 * nh + 8 * (lane & 3))) * 2u;
         v4u hq[4];
         v2u lq[4];
         if constexpr (RES) {   // the old planes of the task's four 16-row steps

@@ -109,6 +109,9 @@ int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* nee
  *   "qkv_pad"    elements added to the row pitch of the bf16 image tower's q|k|v activations where the persistent attention
  *                runs (default 128 = 256 bytes; a multiple of 64 in 0..1024; 0 = dense 3 D rows, the layout of rounds 1-4:
  *                a head's pieces then fall on few memory channels and attention takes 15-20 % longer).  Same bits
+ *   "qkv_layout" how the bf16 image tower keeps q|k|v between the q/k/v GEMM and the persistent attention: 0 = token rows
+ *                [M][3 D + qkv_pad]; 1 = head-major planes [3][H][Mp][64] (the GEMM's epilogue stores one contiguous KiB per
+ *                wave-instruction, attention fetches a head's K / V / q of one image as one contiguous block).  Same bits
  *   "split_tail" 0 = do not cut a short last round of GEMM tiles into quadrant tasks (A/B hook)
  *   "gemm_order" tile order of the persistent GEMM: np > 0 (default 4) = an XCD's concurrent tiles are a (32 / np) x np patch
  *                inside one column group of np weight tiles (which stay in its L2); 0 = row-major.  Same bits; -2.3 % per forward

@@ -215,6 +215,14 @@ def test_attention32_row_pitch_and_pair_order_do_not_change_a_bit(built, monkeyp
         monkeypatch.setenv("MI_OP_ATTN_ORDER", str(order))
         got = ops.attention(qkv, H, PRECISION_BF16)
         assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), (pad, order)
+    # head-major planes [3][H][Mp][64] (option "qkv_layout" = 1): a head's K / V / q of one image is one contiguous block,
+    # the next image's rows lie right behind it and NaN patterns behind the last one — rows >= S must still read as zeros
+    monkeypatch.delenv("MI_OP_ATTN_QKV_PAD")
+    monkeypatch.setenv("MI_OP_ATTN_LAYOUT", "1")
+    for order in (0, 1):
+        monkeypatch.setenv("MI_OP_ATTN_ORDER", str(order))
+        got = ops.attention(qkv, H, PRECISION_BF16)
+        assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), ("planes", order)
 
 
 @pytest.mark.parametrize("prec,tol", [(PRECISION_F32, 2e-6), (PRECISION_BF16, 5e-3)])
@@ -547,9 +555,22 @@ def test_ab_hooks_of_the_bf16_tower_do_not_change_a_bit(l14, ln_fold):
         m.set_option("attn_order", order)
         assert np.array_equal(m.forward(px).view(np.uint32), ref.view(np.uint32)), (pad, order)
         assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32)), (pad, order)
+    # q|k|v as head-major planes, written so by the q/k/v GEMM's epilogue and by the last layer's K|V launch and query
+    # scatter (option "qkv_layout"): other addresses, the same values
+    for layout, order, split in ((1, 1, 1), (1, 0, 0), (0, 1, 1), (1, 1, 1)):
+        m.set_option("qkv_layout", layout)
+        m.set_option("attn_order", order)
+        m.set_option("split_tail", split)
+        assert np.array_equal(m.forward(px).view(np.uint32), ref.view(np.uint32)), ("layout", layout, order, split)
+        assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32)), ("layout", layout, order, split)
+        assert np.array_equal(m.forward(px41[:3]).view(np.uint32), ref41[:3].view(np.uint32)), ("layout, one stream", layout)
     m.set_option("full_last", 1)
+    assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32))
+    m.set_option("qkv_layout", 0)
     m.set_option("qkv_pad", 64)
     assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32))
+    with pytest.raises(Exception):
+        m.set_option("qkv_layout", 2)
     with pytest.raises(Exception):
         m.set_option("qkv_pad", 32)    # 128-byte row segments of the GEMM epilogue: multiples of 64 elements only
     with pytest.raises(Exception):

@@ -10,7 +10,6 @@
 #include "attn_stamps.h"   // defines the kernel's timing hooks; the library build leaves them empty
 #endif
 #include "../../image_search_amd/csrc/attn32_kernels.h"
-#include "attn64_kernels.h"
 using namespace mi;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 __global__ void fill_bf16(bf16_t* p, size_t n, uint64_t seed, float scale) {
@@ -46,14 +45,14 @@ int main(int argc, char** argv) {
         const int pairs = n * H, grid = pairs < 256 ? pairs : 256;
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         for (int shift = 0; shift < 2; ++shift) {
-            const float us = time_us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 0, shift, 1, 3 * D, D); }, 20);
+            const float us = time_us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 0, shift, 1, 3 * D, D, 64u, (uint32_t)D); }, 20);
             printf("attn32<288,257> shift=%d n=%d: %.1f us per launch  (%.0f TFLOP/s, %.2f TB/s of q,k,v,ctx)\n", shift, n, us,
                    4.0 * S * S * 64 * H * n / us * 1e-6, (double)M * 4 * D * 2 / us * 1e-6);
         }
 #ifdef ATTN32_STAMPS
         {
             CK(hipMemset(d_st, 0, 256 * 8 * 8 * 8));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 0, 0, 1, 3 * D, D);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 0, 0, 1, 3 * D, D, 64u, (uint32_t)D);
             CK(hipDeviceSynchronize());
             static unsigned long long h[256 * 8 * 8];
             CK(hipMemcpy(h, d_st, sizeof h, hipMemcpyDeviceToHost));
@@ -68,40 +67,8 @@ int main(int argc, char** argv) {
             }
         }
 #endif
-        const float us1 = time_us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 1, 0, 1, 3 * D, D); }, 20);
+        const float us1 = time_us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 1, 0, 1, 3 * D, D, 64u, (uint32_t)D); }, 20);
         printf("attn32<288,257> first tile only (last layer): %.1f us\n", us1);
-    }
-    {
-        auto kern = attn64_bf16_kernel<288, 257, true>;
-        constexpr int LDS = attn32_lds_bytes(288);
-        const int pairs = n * H, grid = pairs < 256 ? pairs : 256;
-        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        for (int shift = 0; shift < 2; ++shift) {
-            const float us = time_us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, D, H, pairs, 0, shift); }, 20);
-            printf("attn64<288,257> shift=%d n=%d: %.1f us per launch  (%.0f TFLOP/s, %.2f TB/s of q,k,v,ctx)\n", shift, n, us,
-                   4.0 * S * S * 64 * H * n / us * 1e-6, (double)M * 4 * D * 2 / us * 1e-6);
-        }
-#ifdef ATTN32_STAMPS
-        {
-            CK(hipMemset(d_st, 0, 256 * 8 * 8 * 8));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, D, H, pairs, 0, 0);
-            CK(hipDeviceSynchronize());
-            static unsigned long long h[256 * 8 * 8];
-            CK(hipMemcpy(h, d_st, sizeof h, hipMemcpyDeviceToHost));
-            const char* cn[5] = {"own loads landed", "barrier", "prep", "sweep", "stores"};
-            const char* sn[5] = {"own DMA landed", "barrier", "combine", "issue pieces", "split + rest"};
-            for (int w : {0, 3, 4, 7}) {
-                printf("attn64 wave %d (%s), mean shader cycles per pair:", w, w < 4 ? "compute" : "service");
-                for (int j = 0; j < 5; ++j) {
-                    double sum = 0; for (int b = 0; b < grid; ++b) sum += (double)h[((size_t)b * 8 + w) * 8 + j];
-                    printf("  %s %.0f", w < 4 ? cn[j] : sn[j], sum / grid / (pairs / grid));
-                }
-                printf("\n");
-            }
-        }
-#endif
-        const float us1 = time_us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, D, H, pairs, 1, 0); }, 20);
-        printf("attn64<288,257> first tiles only (last layer): %.1f us\n", us1);
     }
     {
         auto kern = attn_bf16_kernel<288, 257>;

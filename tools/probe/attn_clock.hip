@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     const int pairs = n * H, grid = pairs < 256 ? pairs : 256;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto launch = [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 0, 0, order, 3 * D + ATTN32_LD_PAD, D + CTX_PAD); };
+    auto launch = [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 0, 0, order, 3 * D + ATTN32_LD_PAD, D + CTX_PAD, 64u, (uint32_t)D); };
     for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());
     const int reps = (int)(soak_s / 150e-6);

@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
             if (c == 2) hipLaunchKernelGGL(copy16, 2048, 256, 0, 0, (const v4u*)other, (v4u*)other2, big / 16);
             if (c == 3) hipLaunchKernelGGL(read16, 2048, 256, 0, 0, (const v4u*)ctx, ctx_bytes / 16, sink);
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 0, 0, 1, 3 * D, D);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, qkv, ctx, S, D, H, pairs, 0, 0, 1, 3 * D, D, 64u, (uint32_t)D);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (it >= 2) us += ms * 1000;
