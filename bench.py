@@ -74,6 +74,8 @@ def parse_args(argv=None):
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the BASELINE config 1 / 2 sub-lines")
+    ap.add_argument("--front-overlap", type=int, default=None, choices=(0, 1), help="A/B: option front_overlap of the model (the next forward's "
+                    "patch gather + patch GEMM on the copy stream, under the current forward)")
     ap.add_argument("--serial", action="store_true", help="A/B: synchronise after every step (no cross-step overlap)")
     ap.add_argument("--no-prefilter", action="store_true", help="A/B: the query as ONE pass over the fp32 rows (no mirror)")
     ap.add_argument("--prefilter", type=int, default=2, choices=(1, 2), help="mirror of the two-stage exact search: 2 = bytes (default), 1 = bf16")
@@ -116,28 +118,67 @@ def self_launch(args) -> int:
     return rc
 
 
+def _profile_meta():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import profile_meta
+    return profile_meta
+
+
 def gemm_in_situ(batch):
-    """What the persistent GEMM reaches INSIDE the tower, from the committed rocprofv3 kernel statistics of this command
-    run as ONE stream (profiles/r05_bench_kernel_stats_single_stream.csv: kernel durations add up there; in the
-    two-stream run they overlap) — not an observation of this run.  frac = the four linears' FLOPs / their kernel time."""
+    """What the persistent GEMM reaches INSIDE the tower, from the newest committed rocprofv3 kernel statistics of this
+    command run as ONE stream (profiles/rNN_bench_kernel_stats_single_stream.csv: kernel durations add up there; in the
+    two-stream run they overlap) — not an observation of this run, and reported under `roofline.from_profile` only while
+    the profile's stamp (tools/profile_meta.py: batch, model, git blob ids of the kernel sources at the time it was taken)
+    matches the sources this run executes and this run's batch.  frac = the four linears' FLOPs / their kernel time."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r05_bench_kernel_stats_single_stream.csv")
-    try:
-        rows = list(csv.DictReader(open(path)))
-    except OSError:
-        return None
+    import glob
+    import re
+    found = []
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats_single_stream.csv")):
+        mo = re.match(r"r(\d+)_", os.path.basename(f))
+        if mo:
+            found.append((int(mo.group(1)), f))
+    if not found:
+        return {"source": None, "refused": "no profiles/rNN_bench_kernel_stats_single_stream.csv"}
+    path = max(found)[1]
+    pm = _profile_meta()
+    rel = os.path.relpath(path, ROOT)
+    meta, stale = pm.check(path)
+    head = {"source": rel, "source_git_blob": pm.git_blob_id(path)}
+    if stale:
+        return dict(head, refused=stale)
+    if meta.get("batch") != batch:
+        return dict(head, refused=f"the profile was taken at batch {meta.get('batch')}, this run is batch {batch}")
+    rows = list(csv.DictReader(open(path)))
     ns = sum(float(r["TotalDurationNs"]) for r in rows if "gemm_bf16_pp_kernel" in r["Name"])
     calls = max((int(r["Calls"]) for r in rows if "gemm_bf16_pp_kernel<6" in r["Name"]), default=0)
-    forwards = calls / 46.0 if calls else 0   # EPI_RESID24: out_proj + fc2 of layers 0 .. 22
+    forwards = calls / 46.0 if calls else 0   # EPI_RESID24: out_proj + fc2 of layers 0 .. 22 of ViT-L/14 (the stamped model)
     if not forwards or not ns:
-        return None
+        return dict(head, refused="no gemm_bf16_pp_kernel<6> rows in the profile")
     per_forward_ms = ns / forwards / 1e6
     flop = batch * 257 * 2.0 * (3 * 1024 * 1024 + 1024 * 1024 + 2 * 4096 * 1024) * 23   # the 23 full layers the kernel runs
-    return {"source": "profiles/r05_bench_kernel_stats_single_stream.csv (MI_CLIP_PARTS=1 under rocprofv3 --kernel-trace --stats)",
-            "gemm_ms_per_forward": round(per_forward_ms, 3), "forwards_in_profile": round(forwards, 1),
-            "TFLOP_per_s": round(flop / (per_forward_ms * 1e-3) / 1e12, 1),
-            "frac": round(flop / (per_forward_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "note": "epilogues included: bias, the folded LayerNorm, the residual add and the row sums run inside these kernels"}
+    return dict(head, command="MI_CLIP_PARTS=1 rocprofv3 --kernel-trace --stats -- python3 bench.py (tools/round_profile.sh)",
+                gemm_ms_per_forward=round(per_forward_ms, 3), forwards_in_profile=round(forwards, 1),
+                TFLOP_per_s=round(flop / (per_forward_ms * 1e-3) / 1e12, 1),
+                frac=round(flop / (per_forward_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                note="epilogues included: bias, the folded LayerNorm, the residual add and the row sums run inside these kernels")
+
+
+def pmc_traffic(args):
+    """profiles/pmc_latest.json (separate --pmc passes of this command), or (None, reason) when it was not taken on this
+    code at this size"""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        return None, "no profiles/pmc_latest.json"
+    if pmc.get("rows") != args.rows or pmc.get("batch") != args.batch:
+        return None, f"taken at rows={pmc.get('rows')} batch={pmc.get('batch')}"
+    _, stale = _profile_meta().check(path)
+    if stale:
+        return None, stale
+    return pmc, None
 
 
 def cpu_baseline(weights, cfg):
@@ -277,7 +318,6 @@ def sharded_probe(args) -> int:
         ms = (time.perf_counter() - t0) / 24 * 1e3
         out["knn_ms_per_query" + ("_two_stage" if mode else "")] = round(ms, 4)
     out["rows"] = len(big)
-    out["exchange_cost"] = exchange_cost(args, devices[0])
     # 2. scan task + search handler in the one process: a replica per shard, chunks of n x batch images
     models = [Model.from_file(wpath, d, PRECISION_BF16) for d in (devices if n_dev > 1 else devices[:1])]
     if n_dev <= 1:
@@ -312,11 +352,16 @@ def sharded_probe(args) -> int:
         pb.close()
     if own_weights:
         os.unlink(wpath)
+    # last, guarded, and with everything above already measured: on a real multi-GPU node this path has never run
+    try:
+        out["exchange_cost"] = exchange_cost(args, devices[0], float(os.environ.get("MI_BENCH_T_SCAN_MS", "0")) or None)
+    except Exception as e:  # noqa: BLE001
+        out["exchange_cost"] = {"error": f"{type(e).__name__}: {e}"}
     print("SHARDED_PROBE " + json.dumps(out), flush=True)
     return 0
 
 
-def exchange_cost(args, device):
+def exchange_cost(args, device, t_scan=None):
     """What the exchange step itself costs, as far as ONE GPU can say: a one-shard table made with
     the RCCL transport runs the library's real path — ncclAllGather of the packed [k x u64 | k x f32] record on a
     one-rank communicator + the device merge + the readback — against the same table without an exchange.  Blocking
@@ -354,7 +399,10 @@ def exchange_cost(args, device):
         t.close()
     ex_lat = res["rccl_one_rank"]["ms_per_blocking_search_median"] - res["no_exchange"]["ms_per_blocking_search_median"]
     ex_thr = res["rccl_one_rank"]["ms_per_search_pipelined"] - res["no_exchange"]["ms_per_search_pipelined"]
-    t_scan = 1.27   # ms: the two-stage scan of one GPU's 10 M rows (BENCH: knn.ms_per_query)
+    if t_scan is None:   # run by hand: no parent bench measured the 10 M scan
+        res.update({"rows": 1_000_000, "k": args.k, "exchange_ms_blocking": round(ex_lat, 4), "exchange_ms_pipelined": round(ex_thr, 4)})
+        return res
+    # t_scan: the two-stage scan of one GPU's 10 M rows as THIS run measured it (BENCH: knn.ms_per_query)
     res.update({"rows": 1_000_000, "k": args.k,
                 "exchange_ms_blocking": round(ex_lat, 4), "exchange_ms_pipelined": round(ex_thr, 4),
                 "projection_8_gpus": {"t_scan_ms": t_scan, "speedup_blocking": round(8 * t_scan / (t_scan + max(ex_lat, 0.0)), 2),
@@ -363,11 +411,14 @@ def exchange_cost(args, device):
     return res
 
 
-def run_sharded_probe(args, wpath):
+def run_sharded_probe(args, wpath, t_scan_ms=None):
     """the probe as a CHILD with its own deadline: a hang in a multi-GPU runtime call must not take the N = 1 line with it"""
     cmd = [sys.executable, os.path.abspath(__file__), "--sharded-probe", "--batch", str(args.batch), "--k", str(args.k)]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, MI_BENCH_WEIGHTS=wpath))
+        env = dict(os.environ, MI_BENCH_WEIGHTS=wpath)
+        if t_scan_ms:
+            env["MI_BENCH_T_SCAN_MS"] = repr(float(t_scan_ms))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     except subprocess.TimeoutExpired:
         return {"error": "timed out after 240 s"}
     for ln in r.stdout.splitlines():
@@ -397,6 +448,11 @@ def dry_run(args, world, rank):
             mi, md = ex.collect()
             ok = ok and np.array_equal(mi, np.arange(k, dtype=np.uint64)) and \
                 np.array_equal(md, (np.arange(k, dtype=np.uint64).astype(np.float32) / np.float32(1000.0)))
+        # the verdict of EVERY rank, not just rank 0's: all lists identical to the known answer everywhere
+        import torch
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if rank == 0:
@@ -466,6 +522,8 @@ def main():
         log(f"[bench] seeded ViT-L/14 weights written in {time.time() - t0:.1f}s")
     barrier()
     model = Model.from_file(wpath, local, PRECISION_BF16)
+    if args.front_overlap is not None:
+        model.set_option("front_overlap", args.front_overlap)
     total_steps = args.warmup + args.steps
     # the step's input: a batch in PINNED host memory (what the server's decode threads would fill),
     # two buffers so that batch i+1 uploads under the forward of batch i
@@ -696,13 +754,14 @@ def main():
         stream.synchronize()
         a, b = ev(), ev()
         a.record(stream)
-        for _ in range(2):
+        for _ in range(5):
             m32.forward_device(d_img.data_ptr(), nb, d_emb.data_ptr(), stream.cuda_stream)
         b.record(stream)
         stream.synchronize()
-        ms = a.elapsed_time(b) / 2
+        ms = a.elapsed_time(b) / 5
         tf = nb * VIT_FLOP_PER_IMAGE / (ms * 1e-3) / 1e12
-        extra[f"vit_fp32_b{nb}"] = {"config": f"ViT-L/14 image encoder, batch={nb} fp32 (exact-f32 MFMA, the parity path: <= 1e-4 of the oracle), inputs resident",
+        if nb != 32:   # at --batch 32 the line above is this one
+            extra[f"vit_fp32_b{nb}"] = {"config": f"ViT-L/14 image encoder, batch={nb} fp32 (exact-f32 MFMA, the parity path: <= 1e-4 of the oracle), inputs resident",
                                     "ms_per_batch": round(ms, 3), "images_per_sec": round(nb * 1e3 / ms, 1), "TFLOP_per_s": round(tf, 1),
                                     "frac_of_f32_mfma_peak": round(tf / PEAK_F32_TFLOPS, 4)}
         m32.close()
@@ -714,13 +773,9 @@ def main():
         tf_exec = args.batch * executed / (ms_vit * 1e-3) / 1e12
         tf_alg = args.batch * VIT_FLOP_PER_IMAGE / (ms_vit * 1e-3) / 1e12
         knn_gbs = len(table) * 768 * 4 / (ms_knn * 1e-3) / 1e9
-        pmc = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-                pmc = json.load(f)
-        except OSError:
-            pass
-        traffic_ok = bool(pmc) and pmc.get("rows") == args.rows and pmc.get("batch") == args.batch
+        pmc, pmc_refused = pmc_traffic(args)
+        traffic_ok = pmc is not None
+        pmc = pmc or {}
         out = {
             "metric": METRIC,
             "value": round(imgs / elapsed, 2),
@@ -762,8 +817,11 @@ def main():
                          "frac": round(tf_exec / PEAK_BF16_TFLOPS, 4),
                          "traffic": pmc.get("vit_hbm_bytes") if traffic_ok else None,
                          "traffic_source": "profiles/pmc_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                           "(tools/round_profile.sh), NOT an observation of this run; fabric-side bytes incl. Infinity-Cache hits",
-                         "gemm_in_situ": gemm_in_situ(args.batch),
+                                           "(tools/round_profile.sh), NOT an observation of this run; fabric-side bytes incl. Infinity-Cache hits"
+                                           + ("" if traffic_ok else f"; REFUSED: {pmc_refused}"),
+                         "from_profile": {"note": "read from committed profiles, not observed by this run; each entry is refused (no numbers) "
+                                                  "when its stamp does not match the kernel sources and batch of this run",
+                                          "gemm_in_situ": gemm_in_situ(args.batch)},
                          "executed_gflop_per_image": round(executed / 1e9, 2),
                          "algorithmic_gflop_per_image": round(VIT_FLOP_PER_IMAGE / 1e9, 2),
                          "frac_on_algorithmic_flops": round(tf_alg / PEAK_BF16_TFLOPS, 4),
@@ -797,7 +855,7 @@ def main():
         if world == 1 and not args.no_extra_configs:
             # the ONE-process form (mi_knn_sharded + mi_pipeline_create_sharded) over every GPU this process can see, as a
             # child with its own deadline; on a one-GPU box: two shards and two replicas on GPU 0
-            out.setdefault("other_configs", {})["one_process_sharded"] = run_sharded_probe(args, wpath)
+            out.setdefault("other_configs", {})["one_process_sharded"] = run_sharded_probe(args, wpath, ms_knn_two or ms_knn)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(weights, cfg)
         failed = failed or two_stage_equal is False

@@ -26,6 +26,7 @@ SYMBOLS = {
     "mi_weights_list": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     "mi_clip_set_option": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
     "mi_clip_info": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint32)]),
+    "mi_clip_ln_fold_stats": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
     "mi_clip_embed": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "mi_clip_embed_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "mi_clip_embed_rgb8": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),

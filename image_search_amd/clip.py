@@ -133,6 +133,13 @@ class Model:
         """max_batch / parts / full_last / split_tail (include/mi355clip.h: mi_clip_set_option)."""
         check(lib().mi_clip_set_option(self._h, key.encode(), int(value)))
 
+    def ln_fold_stats(self, reset: bool = False):
+        """(rows whose mean lies more than 4 sigma off zero, rows looked at) of the LayerNorm-free layer loop since load /
+        the last reset: non-zero first value on real weights = set option "ln_fold" to 0 (mi_clip_ln_fold_stats)."""
+        out = (ctypes.c_uint64 * 2)()
+        check(lib().mi_clip_ln_fold_stats(self._h, out, 1 if reset else 0))
+        return int(out[0]), int(out[1])
+
 
 class TextModel:
     """The CLIP text tower on one MI355X: what `clip(state, text)` obtains from embed_anything

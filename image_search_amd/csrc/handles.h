@@ -53,9 +53,21 @@ struct mi_clip {
     } act[4];
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    // a forward's front (patch gather + patch GEMM) may run on a stream of its own, under the PREVIOUS forward's layers
+    // (forward(..., front)): ev_embed[p] = the last embed_ln of activation set p has read `patch` (the next front may
+    // overwrite col / patch), ev_front[p] = the front of set p has written `patch` (embed_ln may read it)
+    hipEvent_t ev_embed[4] = {nullptr, nullptr, nullptr, nullptr}, ev_front[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_embed_set[4] = {false, false, false, false};
     bool x24 = true;          // bf16 image tower: the residual stream as 24-bit floats in two planes (3 bytes per element instead of 4; option "x24", MI_CLIP_X24)
     bool ln_fold = true;      // bf16 image tower without LayerNorm kernels in the layer loop where the geometry allows (option "ln_fold", MI_CLIP_LN_FOLD; forward() in vit.hip)
     bool fold_ready = false;  // the folded weights were built at load (geometry allows it)
+    bool ln_center = true;    // fold_ready handles: the common mode of everything written to the residual stream removed at load / in embed_ln (vit.hip: center_writer; MI_CLIP_LN_CENTER)
+    // ln_fold's watch on its own precondition (mi_clip_ln_fold_stats): live rows of the residual stream whose mean lies more
+    // than 4 standard deviations off zero (mean^2 > 16 var) — there bf16(x), taken BEFORE the mean is subtracted, starts to
+    // lose the bits the LayerNorm tower keeps.  Counted on the device by embed_ln_kernel / ln_stats_kernel (an atomic only when a
+    // row trips), rows looked at counted on the host.
+    unsigned long long* d_fold_offset_rows = nullptr;
+    uint64_t fold_rows_checked = 0;
     int parts = 2;  // MI_CLIP_PARTS: sub-chunks run as independent streams
     int n_cu = 256;
     uint8_t* d_rgb = nullptr;
@@ -87,6 +99,7 @@ struct mi_clip {
     bool attn_shift = false;  // force the shifted (exact maximum) pass of attn32 — test hook
     int qkv_pad = 128;        // elements added to the image tower's qkv row pitch where attn32 runs (vit.hip: qkv_pitch)
     int qkv_layout = 0;       // 0 = token rows [M][3D + pad]; 1 = head-major planes [3][H][Mp][64] (vit.hip: qkv_head_major)
+    bool front_overlap = false; // mi_pipeline_ingest / mi_clip_embed: a forward's patch gather + patch GEMM on the copy stream, under the previous forward (option "front_overlap")
     int attn_order = 1;       // attn32: first pair of workgroup b (0 = b; 1 = transposed, an XCD's workgroups spread over all heads)
     bool full_last = false;   // compute the dead rows of the last layer too (A/B against the reference graph)
     bool split_tail = true;   // cut a short last round of GEMM tiles into quadrant tasks
@@ -238,7 +251,7 @@ namespace mi {
 hipStream_t clip_own_stream(mi_clip* m);
 void clip_ensure_workspace(mi_clip* m, size_t n);   // frees and reallocates: waits for the handle's pending work
 void clip_ensure_copy_stream(mi_clip* m);
-void clip_forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t s);
+void clip_forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t s, hipStream_t front = nullptr);
 // knn.hip
 hipStream_t knn_own_stream(mi_knn* t);
 void knn_grow(mi_knn* t, uint64_t want_rows);       // may reallocate: waits for the handle's pending work

@@ -222,7 +222,8 @@ void lane_ingest(mi_pipeline* p, int li, const float* nchw, size_t n) {
         t->writes.begin(ln.ingest);
         HIP_CHECK(hipStreamWaitEvent(ln.ingest, ln.ev_up[b], 0));
         auto& sp = span_begin(p, ln.fwd, &ln.n_fwd, 0, ln.ingest);
-        clip_forward(m, ln.d_in[b], c, t->table + t->rows * t->dim, ln.ingest);
+        // option "front_overlap": the forward's front (the only reader of d_in) on the copy stream, right behind its upload
+        clip_forward(m, ln.d_in[b], c, t->table + t->rows * t->dim, ln.ingest, m->front_overlap ? ln.copy : nullptr);
         span_end(sp, ln.ingest);
         HIP_CHECK(hipEventRecord(ln.ev_used[b], ln.ingest));
         m->order.end(ln.ingest);

@@ -85,6 +85,26 @@ void* upload_mat(mi_clip* m, const std::vector<float>& h, size_t dup_k = 0) {
 
 void load_layers(mi_clip* m, WeightFile& st, const std::string& prefix);
 
+// Every reader of the residual stream is a LayerNorm (LN1, LN2, post_layernorm: modeling_clip.py:353-383, :641-651), and a
+// LayerNorm does not see a constant added to all channels of a row.  So the common mode of everything WRITTEN to the stream
+// can be removed without changing the function: W <- (I - 11^T / N) W (every column loses its mean over the N output
+// channels), b <- b - mean(b), for out_proj and fc2 (here, at load) and the row mean of the pre-LayerNorm's output
+// (embed_ln_kernel).  The rows of the stream then have mean ~ 0, which is what the LayerNorm-free loop needs: it rounds the
+// UN-normalised row to bf16, and a row r sigma off zero pays r times the LayerNorm tower's rounding (measured, DESIGN.md 3.1:
+// in bound up to r = 4, 3 x out of it at r = 16).  Option "ln_center" at load (MI_CLIP_LN_CENTER=0 keeps the weights as read).
+void center_writer(std::vector<float>& w, std::vector<float>& b, int N, int K) {
+    std::vector<double> cm((size_t)K, 0.0);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) cm[(size_t)k] += (double)w[(size_t)n * K + k];
+    for (int k = 0; k < K; ++k) cm[(size_t)k] /= (double)N;
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) w[(size_t)n * K + k] = (float)((double)w[(size_t)n * K + k] - cm[(size_t)k]);
+    double bm = 0.0;
+    for (int n = 0; n < N; ++n) bm += (double)b[(size_t)n];
+    bm /= (double)N;
+    for (int n = 0; n < N; ++n) b[(size_t)n] = (float)((double)b[(size_t)n] - bm);
+}
+
 // LayerNorm(gamma, beta) in front of the linear (W [N][K], b): W' = bf16(W diag(gamma)), c[n] = sum_k W'[n][k] (of the
 // ROUNDED weights: the epilogue subtracts mean * c from what the MFMAs accumulated over exactly those), b' = W beta + b.
 // y = W LN(x) + b = rstd * (W' x - mean * c) + b'   (gemm_bf16_pp_kernel<EPI_LNF>)
@@ -200,6 +220,11 @@ void load_weights(mi_clip* m, const char* path) {
     // the LayerNorm-free layer loop needs the persistent GEMM on all four linears (256-wide tiles) and a last layer to
     // hand over to; the folded copies of W_qkv / W_fc1 are built beside the plain ones (option "ln_fold" switches per forward)
     m->fold_ready = m->precision == MI_PRECISION_BF16 && !m->split_ln && m->D % 256 == 0 && m->FF % 256 == 0 && m->L >= 2;
+    m->ln_center = m->fold_ready && m->ln_center;
+    if (m->fold_ready) {
+        m->d_fold_offset_rows = dalloc<unsigned long long>(m, 1, m->allocs);
+        HIP_CHECK(hipMemset(m->d_fold_offset_rows, 0, sizeof(unsigned long long)));
+    }
     load_layers(m, st, v);
 }
 
@@ -229,8 +254,12 @@ void load_layers(mi_clip* m, WeightFile& st, const std::string& v) {
         }
         ly.wqkv = upload_mat(m, wqkv, m->split_ln ? (size_t)D : 0);
         ly.bqkv = upload_f32(m, bqkv);
-        ly.wo = upload_mat(m, st.read(p + "self_attn.out_proj.weight", (int64_t)D * D));
-        ly.bo = upload_f32(m, st.read(p + "self_attn.out_proj.bias", D));
+        {
+            std::vector<float> wo = st.read(p + "self_attn.out_proj.weight", (int64_t)D * D), bo = st.read(p + "self_attn.out_proj.bias", D);
+            if (m->ln_center) center_writer(wo, bo, D, D);
+            ly.wo = upload_mat(m, wo);
+            ly.bo = upload_f32(m, bo);
+        }
         const std::vector<float> w1 = st.read(p + "mlp.fc1.weight", (int64_t)FF * D), b1 = st.read(p + "mlp.fc1.bias", FF);
         ly.w1 = upload_mat(m, w1, m->split_ln ? (size_t)D : 0);
         ly.b1 = upload_f32(m, b1);
@@ -238,8 +267,12 @@ void load_layers(mi_clip* m, WeightFile& st, const std::string& v) {
             fold_ln(m, wqkv, bqkv, st.read(p + "layer_norm1.weight", D), st.read(p + "layer_norm1.bias", D), 3 * D, D, &ly.wqkv_f, &ly.cqkv, &ly.bqkv_f);
             if (i + 1 < L) fold_ln(m, w1, b1, st.read(p + "layer_norm2.weight", D), st.read(p + "layer_norm2.bias", D), FF, D, &ly.w1_f, &ly.c1, &ly.b1_f);
         }
-        ly.w2 = upload_mat(m, st.read(p + "mlp.fc2.weight", (int64_t)D * FF));
-        ly.b2 = upload_f32(m, st.read(p + "mlp.fc2.bias", D));
+        {
+            std::vector<float> w2 = st.read(p + "mlp.fc2.weight", (int64_t)D * FF), b2 = st.read(p + "mlp.fc2.bias", D);
+            if (m->ln_center) center_writer(w2, b2, D, FF);
+            ly.w2 = upload_mat(m, w2);
+            ly.b2 = upload_f32(m, b2);
+        }
     }
 }
 
@@ -517,7 +550,11 @@ bool fold_applies(const mi_clip* m, size_t rows_max) {
 //    per-row partial sums (EPI_RESID24), which ln_stats_kernel turns into the next {rstd, -mean rstd}.  The last layer
 //    runs on LayerNorm kernels again (it works on the CLS rows only).
 // fp32 path: the residual add is the GEMM epilogue (x += acc + bias, fp32 read-modify-write).
-void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t s0) {
+// front != nullptr: the patch gather and the patch GEMM (the only readers of d_img and the only writers of col / patch) are
+// enqueued on that stream instead of the parts' own — a caller that has just uploaded d_img on it (mi_pipeline_ingest: the
+// copy stream) lets them run under the PREVIOUS forward's layers, which never touch those buffers; events order them against
+// the embed_ln kernels on either side.  Same kernels, same arguments: same bits.
+void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t s0, hipStream_t front = nullptr) {
     const int D = m->D, S = m->S, FF = m->FF;
     const size_t px = (size_t)m->image * m->image * 3;
     const bool deferred = m->precision == MI_PRECISION_BF16;
@@ -545,7 +582,13 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     }
     for (int p = 0; p < parts; ++p) {
         Part& q = pt[p];
-        hipStream_t fs = q.s;
+        hipStream_t es_ = q.s;                 // embed_ln and everything behind it
+        hipStream_t fs = front ? front : q.s;  // the front
+        if (!m->ev_embed[p]) {
+            HIP_CHECK(hipEventCreateWithFlags(&m->ev_embed[p], hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&m->ev_front[p], hipEventDisableTiming));
+        }
+        if (front && m->ev_embed_set[p]) HIP_CHECK(hipStreamWaitEvent(front, m->ev_embed[p], 0));
         // patch embedding: gather -> GEMM [P,Kp] x [D,Kp]^T -> f32
         const size_t total = q.P * 3 * (size_t)m->patch;  // one thread per patch-row segment
         const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65535 * 4);
@@ -558,10 +601,18 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
             hipLaunchKernelGGL((im2col_kernel<bf16_t>), dim3(blocks), dim3(256), 0, fs, q.img, (bf16_t*)q.a->col, (int)q.n, m->grid, m->patch, m->image, m->Kp);
         HIP_CHECK(hipGetLastError());
         gemm<EPI_STORE_F32>(m, q.a->col, m->wpatch, nullptr, q.a->patch, q.P, D, m->Kp, D, fs);
+        if (front) {
+            HIP_CHECK(hipEventRecord(m->ev_front[p], front));
+            HIP_CHECK(hipStreamWaitEvent(es_, m->ev_front[p], 0));
+        }
+        fs = es_;
         const size_t rows_launch = fold ? pad256(q.M) : q.M;   // ln_fold: the padding rows get a defined (zero) residual too
         const unsigned lb = (unsigned)((rows_launch + 3) / 4);
         MI_LN_DISPATCH(D, hipLaunchKernelGGL((embed_ln_kernel<VEC, NT>), dim3(lb), dim3(256), 0, fs, q.a->patch, m->cls, m->pos, q.a->x, m->pre_w, m->pre_b, (int)q.M, S, m->eps, q.xlo,
-                                             fold ? q.a->stats : (float*)nullptr, (int)rows_launch));
+                                             fold ? q.a->stats : (float*)nullptr, (int)rows_launch, fold ? m->d_fold_offset_rows : nullptr, m->ln_center ? 1 : 0));
+        if (fold) m->fold_rows_checked += q.M;
+        HIP_CHECK(hipEventRecord(m->ev_embed[p], fs));   // `patch` has been read: a later forward's front may overwrite it
+        m->ev_embed_set[p] = true;
         HIP_CHECK(hipGetLastError());
     }
     // The pooled output is the CLS row (modeling_clip.py:641-651), so behind the LAST layer's attention
@@ -578,8 +629,10 @@ void forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t
     const int ldq_o = hm ? 64 : ldq;   // the q/k/v GEMM's output row pitch
     auto ln_stats = [&](Part& q) {   // the partial sums of the GEMM just enqueued -> {rstd, -mean rstd} per (padded) row
         const size_t Mp = pad256(q.M);
-        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(Mp / 16)), dim3(256), 0, q.s, q.a->part, q.a->stats, (int)Mp, nb, 1.0f / (float)D, m->eps);
+        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(Mp / 16)), dim3(256), 0, q.s, q.a->part, q.a->stats, (int)Mp, nb, 1.0f / (float)D, m->eps,
+                           (int)q.M, m->d_fold_offset_rows);
         HIP_CHECK(hipGetLastError());
+        m->fold_rows_checked += q.M;
     };
     for (size_t li = 0; li < m->layers.size(); ++li) {
         const Layer& ly = m->layers[li];
@@ -868,6 +921,8 @@ void free_model(mi_clip* m) {
     for (auto& a : m->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
     m->order.destroy();
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    for (auto& e : m->ev_embed) if (e) (void)hipEventDestroy(e);
+    for (auto& e : m->ev_front) if (e) (void)hipEventDestroy(e);
     for (auto& e : m->ev_join) if (e) (void)hipEventDestroy(e);
     if (m->copy_stream) { (void)hipStreamSynchronize(m->copy_stream); (void)hipStreamDestroy(m->copy_stream); }
     for (int b = 0; b < 2; ++b) {
@@ -890,7 +945,7 @@ namespace mi {
 hipStream_t clip_own_stream(mi_clip* m) { return own_stream(m); }
 void clip_ensure_workspace(mi_clip* m, size_t n) { ensure_workspace(m, n); }
 void clip_ensure_copy_stream(mi_clip* m) { ensure_copy_stream(m); }
-void clip_forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t s) { forward(m, d_img, n, d_out, s); }
+void clip_forward(mi_clip* m, const float* d_img, size_t n, float* d_out, hipStream_t s, hipStream_t front) { forward(m, d_img, n, d_out, s, front); }
 }  // namespace mi
 
 extern "C" {
@@ -926,6 +981,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         if (m->text) { m->order.sync(); drop_text_graph(m); }
         if (k == "full_last") m->full_last = value != 0;
         else if (k == "attn_shift") m->attn_shift = value != 0;
+        else if (k == "front_overlap") m->front_overlap = value != 0;
         else if (k == "qkv_pad") {   // the activation sets are sized by it: rebuild on next use
             if (value < 0 || value > 1024 || value % 64) fail(MI_ERR_INVALID, "qkv_pad must be a multiple of 64 in 0..1024");
             if (m->text) fail(MI_ERR_INVALID, "the text tower's qkv rows are dense");
@@ -973,7 +1029,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, attn_shift, attn_order, qkv_pad, qkv_layout, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, text_fuse, attn_f32_mfma, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, front_overlap, attn_shift, attn_order, qkv_pad, qkv_layout, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, text_fuse, attn_f32_mfma, max_batch, parts)", key);
     });
 }
 
@@ -1003,7 +1059,9 @@ int mi_clip_load(const char* weights_path, int device, int precision, mi_clip** 
         if (const char* e = std::getenv("MI_CLIP_IM2COL")) m->im2col_rows = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_CLIP_LN_NT")) m->ln_nt = std::atoi(e) & 3;
         if (const char* e = std::getenv("MI_CLIP_X24")) m->x24 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MI_CLIP_LN_CENTER")) m->ln_center = std::atoi(e) != 0;   // fixed at load: it shapes the weights
         if (const char* e = std::getenv("MI_CLIP_QKV_LAYOUT")) m->qkv_layout = std::atoi(e) == 1 ? 1 : 0;
+        if (const char* e = std::getenv("MI_CLIP_FRONT_OVERLAP")) m->front_overlap = std::atoi(e) != 0;
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         m->n_cu = prop.multiProcessorCount;
@@ -1088,6 +1146,25 @@ int mi_clip_info(const mi_clip* m, uint32_t out[8]) {
     });
 }
 
+int mi_clip_ln_fold_stats(mi_clip* m, uint64_t out[2], int reset) {
+    return guarded([&] {
+        if (!m || !out) fail(MI_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> l(m->mu);
+        DeviceGuard g(m->device);
+        out[0] = out[1] = 0;
+        if (!m->d_fold_offset_rows) return;   // no LayerNorm-free loop on this handle: nothing was ever looked at
+        m->order.sync();                      // the forwards enqueued so far have counted
+        unsigned long long v = 0;
+        HIP_CHECK(hipMemcpy(&v, m->d_fold_offset_rows, sizeof v, hipMemcpyDeviceToHost));
+        out[0] = v;
+        out[1] = m->fold_rows_checked;
+        if (reset) {
+            HIP_CHECK(hipMemset(m->d_fold_offset_rows, 0, sizeof v));
+            m->fold_rows_checked = 0;
+        }
+    });
+}
+
 int mi_clip_embed_device(mi_clip* m, const float* d_nchw, size_t n, float* d_out, void* stream) {
     return guarded([&] {
         if (!m) fail(MI_ERR_INVALID, "null model handle");
@@ -1140,7 +1217,7 @@ int mi_clip_embed(mi_clip* m, const float* nchw, size_t n, float* out) {
             const size_t i = ci * chunk, c = std::min(chunk, n - i);
             const int b = (int)(ci & 1);
             HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_up[b], 0));
-            forward(m, din[b], c, dout[b], m->stream);
+            forward(m, din[b], c, dout[b], m->stream, m->front_overlap ? m->copy_stream : nullptr);
             HIP_CHECK(hipEventRecord(m->ev_used[b], m->stream));
             if (ci + 1 < nchunks) upload(ci + 1);  // pageable source: blocks this thread while the GPU computes
             HIP_CHECK(hipMemcpyAsync(out + i * m->E, dout[b], c * m->E * 4, hipMemcpyDeviceToHost, m->stream));

@@ -395,12 +395,21 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const bf
 }
 // token assembly + pre-LN (modeling_clip.py:198-218, :641-651):
 // x[b*S+s] = LN_pre((s == 0 ? cls : patch[b*(S-1)+s-1]) + pos[s])
+// ln_fold feeds q/k/v and fc1 the bf16 rounding of the UN-normalised residual row: with |mean| = r sigma every element carries
+// an error of up to 2^-9 r sigma, i.e. about r times what rounding the normalised value costs.  Measured on ViT-L/14
+// (tools/bf16_acceptance.py; max error / rms against fp32, bound 3e-2): r = 0, 1: 1.5e-2 (= the LayerNorm
+// tower); r = 4: 2.3e-2; r = 16: 8.8e-2; r = 64: 0.30.  Rows with mean^2 > 16 var (r > 4) are counted
+// (mi_clip_ln_fold_stats).  The tower removes the common mode of everything it writes to the stream (center_writer), so on
+// handles loaded that way the count stays 0 whatever the checkpoint's biases are; it is the check, not the cure.
+constexpr float LN_FOLD_OFFSET_LIMIT = 16.0f;
+
 template <int VEC, int NT>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
                                                        const float* __restrict__ pos, float* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ b,
                                                        int rows, int S, float eps, size_t x_lo_off = 0,
-                                                       float* __restrict__ stats = nullptr, int rows_pad = 0) {
+                                                       float* __restrict__ stats = nullptr, int rows_pad = 0,
+                                                       unsigned long long* __restrict__ offset_rows = nullptr, int center = 0) {
     constexpr int D = 64 * VEC * NT;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -418,6 +427,14 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
                 r.add(pos + (size_t)s * D, lane);
                 r.normalize(w, b, eps, lane);
                 constexpr float inv = 1.0f / D;
+                if (center) {   // the stream's readers are LayerNorms: the row's common mode may go (vit.hip: center_writer)
+                    float s0 = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < VEC * NT; ++j) s0 += r.v[j];
+                    const float m0 = wave_sum(s0) * inv;
+#pragma unroll
+                    for (int j = 0; j < VEC * NT; ++j) r.v[j] -= m0;
+                }
                 float sm = 0.0f;
 #pragma unroll
                 for (int j = 0; j < VEC * NT; ++j) sm += r.v[j];
@@ -425,8 +442,11 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
                 float q = 0.0f;
 #pragma unroll
                 for (int j = 0; j < VEC * NT; ++j) { const float d = r.v[j] - mean; q = __builtin_fmaf(d, d, q); }
-                st_a = 1.0f / sqrtf(wave_sum(q) * inv + eps);
+                const float var = wave_sum(q) * inv;
+                st_a = 1.0f / sqrtf(var + eps);
                 st_b = -mean * st_a;
+                // ln_fold's precondition (LN_FOLD_OFFSET_LIMIT): a row this far off zero has lost its bits in the hi plane
+                if (offset_rows && lane == 0 && mean * mean > LN_FOLD_OFFSET_LIMIT * var) atomicAdd(offset_rows, 1ull);
             } else {
 #pragma unroll
                 for (int j = 0; j < VEC * NT; ++j) r.v[j] = 0.0f;
@@ -1127,8 +1147,10 @@ __device__ __forceinline__ void resid24_step(const v4u h, const v2u l, const v4u
 // as a fixed butterfly (l ^ 1, l ^ 2, mirror in 8, mirror in 16) — one order, whatever the launch.
 // var = E[x^2] - mean^2 in fp32 on fp32 partial sums: fine while |mean| is not orders of magnitude above the deviation
 // (a pre-LN residual stream's never is).
+// rows_live / offset_rows: rows < rows_live with mean^2 > LN_FOLD_OFFSET_LIMIT * var are counted (see embed_ln_kernel).
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ part, float* __restrict__ stats, int rows, int nb,
-                                                       float inv_d, float eps) {
+                                                       float inv_d, float eps, int rows_live = 0,
+                                                       unsigned long long* __restrict__ offset_rows = nullptr) {
     const int row = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15;
     if (row >= rows) return;   // whole 16-lane groups leave together: the DPP adds below stay inside a group
     const v4f* p = reinterpret_cast<const v4f*>(part + (size_t)row * nb * 2);
@@ -1145,7 +1167,10 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
     const float mean = s * inv_d;
     const float var = fmaxf(q * inv_d - mean * mean, 0.0f);
     const float rstd = 1.0f / sqrtf(var + eps);
-    if (j == 0) *reinterpret_cast<v2f*>(stats + (size_t)row * 2) = (v2f){rstd, -mean * rstd};
+    if (j == 0) {
+        *reinterpret_cast<v2f*>(stats + (size_t)row * 2) = (v2f){rstd, -mean * rstd};
+        if (row < rows_live && mean * mean > LN_FOLD_OFFSET_LIMIT * var) atomicAdd(offset_rows, 1ull);
+    }
 }
 
 // ------------------------------------------------------------------ bf16 GEMM, persistent, two staggered wave groups

@@ -101,6 +101,10 @@ int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* nee
  *   "parts"      1..4 sub-chunks of a pass run as independent streams (default 2; bf16 tower)
  *   "full_last"  1 = also compute the rows of the last layer that never reach the output (default 0:
  *                the pooled output is the CLS row, the result is bit-identical either way)
+ *   "front_overlap" 1 = where the library uploads the images itself (mi_pipeline_ingest, mi_clip_embed) a forward's front — the
+ *                patch gather and the patch GEMM, the only readers of the uploaded batch — is enqueued on the copy stream right
+ *                behind its upload and runs under the PREVIOUS forward's layers (events order it against the embed kernels on
+ *                either side).  Same bits.  mi_pipeline_stats' forward time then starts at the embed kernel
  *   "attn_shift" 1 = always take the shifted (exact row maximum) pass of the bf16 attention (default 0: taken
  *                only for queries whose softmax numerators leave the exponent range; same result)
  *   "attn_order" which (image, head) pairs a workgroup of the persistent bf16 attention walks: 1 (default) = the 32 workgroups
@@ -138,6 +142,24 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value);
 /* geometry of a loaded model: out[0..7] = image, patch, tokens, hidden, layers,
  * heads, ff, proj */
 int mi_clip_info(const mi_clip* m, uint32_t out[8]);
+
+/* The LayerNorm-free layer loop ("ln_fold", the bf16 image tower's default) watches its own precondition.  It feeds the
+ * q/k/v and fc1 GEMMs bf16(x) of the UN-normalised residual row, so a row whose mean lies r standard deviations off zero
+ * carries about r times the rounding error of the LayerNorm tower (which rounds after subtracting the mean).  Measured on
+ * seeded ViT-L/14 with a common offset planted on the stream (tools/bf16_acceptance.py; max error / rms against
+ * the fp32 tower, stated bound 3e-2): r = 0, 1: 1.5e-2, where the LayerNorm tower is; r = 4: 2.3e-2; r = 16: 8.8e-2 (out of
+ * bound, top-1 agreement 96 % instead of 99 %); r = 64: 0.30.  A single massive channel (100 sigma) is harmless: it moves the
+ * deviation, not the mean.
+ * Two defences.  (1) At load the library removes the common mode of everything that writes to the residual stream (out_proj
+ * and fc2 weights and biases, the pre-LayerNorm's output): every reader of the stream is a LayerNorm, so the function is
+ * unchanged and the rows have mean ~ 0 whatever the checkpoint's biases are (MI_CLIP_LN_CENTER=0 at load keeps the weights as
+ * read; with it the r = 64 study reads 1.5e-2 again).  (2) Every forward counts, on the device, the live token rows (all
+ * layers) with mean^2 > 16 var (r > 4):
+ *   out[0] = such rows since load / the last reset,  out[1] = rows looked at.
+ * out[0] != 0: set option "ln_fold" to 0 (LayerNorm kernels, +6 % per forward, insensitive to r).
+ * Waits for the handle's enqueued forwards.  Handles without the loop (fp32, BF16_SPLIT, text, other geometries) report 0, 0.
+ * The reference loads whatever checkpoint -w names (server/src/clip.rs:46-48): this is the check that goes with it. */
+int mi_clip_ln_fold_stats(mi_clip* m, uint64_t out[2], int reset);
 
 /* Replaces `model.forward(Tensor::from_data(TensorData::new(buf,[n,3,224,224])))`
  * + `output.to_data()` (server/src/clip.rs:112-124).  Host pointers.

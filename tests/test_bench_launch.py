@@ -42,6 +42,29 @@ def test_torchrun_form_still_works(built):
     assert out["n_gpus"] == 2 and out["exchange_ok"] is True
 
 
+def test_the_drivers_scale_command_at_its_own_n_of_8(built):
+    """The round-end SCALE run is `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 --steps K --warmup W`; with --dry-run the same command line rehearses here on 8 gloo
+    ranks: rendezvous, the packed all-gather of 8 per-rank lists, mi_knn_merge, the known merged answer on EVERY rank."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = _env()
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2",
+                        "--dry-run"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 8 and out["steps"] == 5 and out["warmup"] == 2 and out["exchange_ok"] is True and out["scaling"] == "weak"
+
+
+def test_bare_gpus_8_launches_its_own_ranks(built):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run", "--k", "1000"],
+                       capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 8 and out["dry_run"] is True and out["exchange_ok"] is True
+
+
 def test_a_failing_rank_fails_the_launcher(built):
     # an argument the ranks reject: the child's exit code must come through, and no result line
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--k", "0"],

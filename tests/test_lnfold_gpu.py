@@ -256,6 +256,53 @@ def test_mid_tower_ln_fold_within_the_bf16_bound_and_chunking(mid, monkeypatch):
     m.close()
 
 
+def test_ln_fold_counts_the_rows_its_rounding_cannot_serve_and_centering_keeps_them_away(mid, tmp_path, monkeypatch):
+    """The LayerNorm-free loop rounds the UN-normalised residual row to bf16; a row whose mean lies r sigma off zero pays about
+    r times the LayerNorm tower's rounding.  A constant on every channel of pre_layrnorm.bias plants such a common offset
+    without changing the function (every later LayerNorm removes it).
+    Weights as read (MI_CLIP_LN_CENTER=0): the library counts, on the device, the live rows with mean^2 > 16 var
+    (mi_clip_ln_fold_stats) — none at 0 and 2 sigma, every row looked at at 64 sigma, where the fold's error has left the
+    LayerNorm tower's far behind; "ln_fold" = 0, the switch the header names, restores it.
+    Default load: the common mode of everything written to the stream is removed (the function does not change: every reader is
+    a LayerNorm), so the same checkpoints give the error of the unplanted one and a count of zero."""
+    cfg, w, path = mid
+    n = 5
+    S = (cfg.image // cfg.patch) ** 2 + 1
+    px = synth.preprocess_rgb8(synth.images_u8(203, n, cfg.image))
+    ref = vit_numpy.vit_forward(w, cfg, px, np.float64)
+    rms = float(np.sqrt((ref ** 2).mean()))
+    looked_at = n * S * (1 + 2 * (cfg.layers - 1))   # the embedding's statistics + two per LayerNorm-free layer
+    name = [k for k in w if k.endswith("pre_layrnorm.bias")][0]
+    errs = {}
+    for center in (0, 1):
+        monkeypatch.setenv("MI_CLIP_LN_CENTER", str(center))
+        for c in (0.0, 2.0, 64.0):
+            wc = dict(w)
+            wc[name] = w[name] + np.float32(c)
+            pc = str(tmp_path / f"offset_{int(c)}.safetensors")
+            synth.save_safetensors(wc, pc, {"num_attention_heads": cfg.heads})
+            m = Model.from_file(pc, 0, PRECISION_BF16)
+            assert m.ln_fold_stats() == (0, 0)
+            out = m.forward(px)
+            bad, seen = m.ln_fold_stats(reset=True)
+            assert seen == looked_at, (c, seen, looked_at)
+            assert m.ln_fold_stats() == (0, 0)
+            m.set_option("ln_fold", 0)
+            base = m.forward(px)
+            assert m.ln_fold_stats() == (0, 0)            # the LayerNorm tower neither needs nor feeds the counter
+            m.close()
+            errs[center, c] = (float(np.abs(out - ref).max() / rms), float(np.abs(base - ref).max() / rms), bad)
+    print({k: tuple(round(v, 5) if isinstance(v, float) else v for v in e) for k, e in errs.items()})
+    for key, (e_fold, e_ln, bad) in errs.items():
+        assert e_ln < 3e-2, key                            # the LayerNorm tower does not care, centred weights or not
+    assert errs[0, 0.0][2] == 0 and errs[0, 2.0][2] == 0 and errs[0, 2.0][0] < 3e-2
+    assert errs[0, 64.0][2] == looked_at                   # weights as read: every row is flagged ...
+    assert errs[0, 64.0][0] > 4.0 * errs[0, 64.0][1]       # ... and the fold's error shows why
+    for c in (0.0, 2.0, 64.0):                             # the default load: no offset reaches the stream
+        assert errs[1, c][2] == 0, c
+        assert errs[1, c][0] < 3e-2 and errs[1, c][0] < 2.0 * max(errs[1, c][1], errs[1, 0.0][0]), (c, errs[1, c])
+
+
 def test_a_nan_in_one_image_stays_a_nan_and_stays_in_that_image(mid):
     """The residual planes carry NaN / Inf patterns through their encode / decode (an integer add on the bit pattern), the row
     statistics of a poisoned row are NaN, and nothing of it may reach another image of the batch."""

@@ -116,6 +116,47 @@ def test_config4_batch256_bf16_embed_append_query(l14_batch, orc, prefilter):
     m.close()
 
 
+@pytest.mark.parametrize("prec", [PRECISION_BF16, PRECISION_F32])
+def test_the_reference_default_chunk_of_500_images(l14_batch, prec):
+    """`-c/--chunk-size` defaults to 500 (server/src/server_arguments.rs:12-13) and a chunk is ONE forward call
+    (server/src/clip.rs:72-73, :112-118); the library's passes hold at most max_batch = 256 images, so the default call runs
+    as 256 + 244 (a ragged second pass of the full geometry), and 257 images as 256 + 1 (a second pass of one image, below
+    the two-stream threshold).  Every row must carry the bits of the pass it would get alone — through the host entry
+    point, through Pipeline.ingest with a 500-image pinned buffer, and with a forward's front overlapped with the previous
+    forward (option "front_overlap")."""
+    cfg, path, px, ref = l14_batch
+    px500 = np.concatenate([px, px[:244][::-1]])
+    m = Model.from_file(path, 0, prec)
+    first, second = m.forward(px500[:256]), m.forward(px500[256:])
+    want = np.concatenate([first, second])
+    assert np.isfinite(want).all()
+    ok, err = close(first[SEL], ref, 1e-4 if prec == PRECISION_F32 else 3e-2)
+    assert ok, err
+    whole = m.forward(px500)
+    assert np.array_equal(whole.view(np.uint32), want.view(np.uint32))
+    one_more = m.forward(px500[:257])
+    assert np.array_equal(one_more.view(np.uint32), np.concatenate([first, m.forward(px500[256:257])]).view(np.uint32))
+    t = EmbeddingTable(768, 0)
+    t.reserve(2000)
+    pipe = Pipeline(m, t)
+    pin = PinnedBuffer(px500.shape)
+    pin.array[:] = px500
+    for overlap in (0, 1):
+        m.set_option("front_overlap", overlap)
+        at = len(t)
+        assert pipe.ingest(pin.array) == at               # 256 + 244 inside one call
+        assert pipe.ingest(pin.array[:257]) == at + 500   # 256 + 1
+        pipe.sync()
+        rows = t.rows(at, 757)
+        assert np.array_equal(rows[:500].view(np.uint32), want.view(np.uint32)), overlap
+        assert np.array_equal(rows[500:].view(np.uint32), one_more.view(np.uint32)), overlap
+        assert np.array_equal(m.forward(px500).view(np.uint32), want.view(np.uint32)), overlap   # mi_clip_embed: two chunks, its own copy stream
+    pipe.close()
+    pin.close()
+    t.close()
+    m.close()
+
+
 def test_handles_order_work_across_streams(l14_batch, orc):
     """embed_device(stream A) -> append_device(stream A) -> search on ANOTHER stream / the handle's own,
     no host synchronisation in between: the search must scan the appended rows (the handle
@@ -191,8 +232,9 @@ def test_pipeline_argument_errors(built, tmp_path):
 def test_bf16_retrieval_agrees_with_fp32_and_outlier_channels_do_not_matter(built, tmp_path):
     """What the bf16 tower costs downstream (profiles/r02_bf16_acceptance.json holds the 4096-image run of
     tools/bf16_acceptance.py): the same structured images indexed from fp32 and from bf16 embeddings, held-out
-    queries embedded in the index's own precision.  Pinned here on 1024 + 50 images:
-      * seeded weights: top-10 / top-100 id sets agree >= 99 %, the nearest image is the same;
+    queries embedded in the index's own precision.  Pinned here on 1024 + 200 images (50 queries made the top-1 line a
+    coin: one flipped near-tie is 2 %; the 1000-query runs of profiles/r06_bf16_acceptance.json read 99.1-99.6 %):
+      * seeded weights: top-10 / top-100 id sets agree >= 99 %, the nearest image is the same for >= 97 %;
       * channels 50x above the rest planted WITHOUT changing the function (LayerNorm gain x50, the matching
         q/k/v/fc1 input columns /50): nothing changes — a float keeps its relative precision at any magnitude;
       * the same channels planted so that the function changes (attention logits ~10x: sharply peaked softmax):
@@ -201,7 +243,7 @@ def test_bf16_retrieval_agrees_with_fp32_and_outlier_channels_do_not_matter(buil
     cfg = synth.VitConfig.vit_l14()
     w = synth.vit_weights(cfg, 0)
     px_i = synth.preprocess_rgb8(synth.scenes_u8(5, 1024, cfg.image))
-    px_q = synth.preprocess_rgb8(synth.scenes_u8(6, 50, cfg.image))
+    px_q = synth.preprocess_rgb8(synth.scenes_u8(6, 200, cfg.image))
 
     def run(weights, prec):
         path = str(tmp_path / "w.safetensors")
@@ -235,7 +277,7 @@ def test_bf16_retrieval_agrees_with_fp32_and_outlier_channels_do_not_matter(buil
     for name in ("generated", "outliers, function preserved"):
         err, agree = report[name]["bf16"]
         assert err <= 3e-2, (name, err)
-        assert agree[1] >= 0.98 and agree[10] >= 0.99 and agree[100] >= 0.99, (name, agree)
+        assert agree[1] >= 0.97 and agree[10] >= 0.99 and agree[100] >= 0.99, (name, agree)
     err16, _ = report["outliers, function changed"]["bf16"]
     errsp, agree_sp = report["outliers, function changed"]["bf16_split"]
     assert err16 <= 6e-2 and errsp <= err16 * 1.05 and agree_sp[10] >= 0.97, report["outliers, function changed"]
