@@ -529,7 +529,9 @@ void layer_norm_x(mi_clip* m, float* x, const bf16_t* d1, const bf16_t* d2, bool
 // can this forward run without LayerNorm kernels in the layer loop (option "ln_fold")?
 bool fold_applies(const mi_clip* m, size_t rows_max) {
     const size_t Mp = pad256(rows_max);
-    return m->ln_fold && m->fold_ready && !m->text && pp_shape_ok(Mp, 3 * m->D, m->D, 3 * m->D) && pp_shape_ok(Mp, m->D, m->D, m->D) &&
+    const int ldq = (int)qkv_pitch(m);   // the q/k/v launch and the last layer's K | V launch write rows of the PADDED pitch
+    return m->ln_fold && m->fold_ready && !m->text && pp_shape_ok(Mp, 3 * m->D, m->D, ldq) && pp_shape_ok(Mp, 2 * m->D, m->D, ldq) &&
+           pp_shape_ok(Mp, m->D, m->D, m->D) &&
            pp_shape_ok(Mp, m->FF, m->D, m->FF) && pp_shape_ok(Mp, m->D, m->FF, m->D) && Mp * (size_t)(m->D / 32) * 8 < (1ull << 32);
 }
 
@@ -548,7 +550,8 @@ bool fold_applies(const mi_clip* m, size_t rows_max) {
 //    q/k/v and fc1 read that plane as it lies, with gamma folded into their weights, and finish the LayerNorm in their
 //    epilogue from per-row {rstd, -mean rstd} (EPI_LNF); out_proj / fc2 add their output to the planes in place and emit
 //    per-row partial sums (EPI_RESID24), which ln_stats_kernel turns into the next {rstd, -mean rstd}.  The last layer
-//    runs on LayerNorm kernels again (it works on the CLS rows only).
+//    folds its LN1 too (K | V of every token and the CLS rows' queries by two EPI_LNF launches) and keeps LayerNorm kernels
+//    for what runs on the CLS rows only (LN2 on n rows, the head).
 // fp32 path: the residual add is the GEMM epilogue (x += acc + bias, fp32 read-modify-write).
 // front != nullptr: the patch gather and the patch GEMM (the only readers of d_img and the only writers of col / patch) are
 // enqueued on that stream instead of the parts' own — a caller that has just uploaded d_img on it (mi_pipeline_ingest: the

@@ -131,7 +131,8 @@ int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* nee
  *                hidden and intermediate sizes that are multiples of 256 and at least two layers (MI_ERR_UNSUPPORTED when
  *                set to 1 on another geometry; such handles silently keep the LayerNorm kernels).  0 = LayerNorm kernels
  *                (rounds 1-4).  -5.7 % per forward; error against fp32 unchanged; a different rounding sequence, so NOT the
- *                same bits as 0.  "x24" and "ln_nt" only act on the LayerNorm form
+ *                same bits as 0.  "x24" and "ln_nt" only act on the LayerNorm form.  Both weight forms stay resident
+ *                so that the option switches per forward: + 0.35 GB per bf16 ViT-L/14 handle (W_qkv, W_fc1 plain and folded)
  *   "attn_f32_mfma" 0 = the fp32 path's attention as one thread per query (rounds 1-4) instead of the exact-f32 MFMA kernel
  *                (another summation order, both far inside 1e-4; A/B hook)
  *   "text_fast"  0 = a single text query takes the batched kernels instead of the skinny-GEMM path (text handles)
