@@ -56,6 +56,9 @@ __device__ __forceinline__ bf16x8 pack8(const v16f& s, int base) {
 
 constexpr float ATTN32_C2 = 0.125f * 1.4426950408889634f;  // scale * log2(e)
 
+#ifndef ATTN32_DMA_AUX
+#define ATTN32_DMA_AUX 0  // cache policy of the K / V LDS-DMA where the template argument is not given: 0 = default, 2 = nt (probe builds sweep it)
+#endif
 #ifndef ATTN32_QSPREAD
 #define ATTN32_QSPREAD 1  // the next pair's query fragments: one load per key step (1) or all four behind the barrier (0)
 #endif
@@ -469,7 +472,13 @@ __host__ __device__ constexpr int attn32_lds_bytes(int s_pad) { return 2 * (2 * 
 #define ATTN32_STAMP_END
 #endif
 #define ATTN32_BARRIER { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); }
-template <int S_PAD, int S_CT, bool PRESCALED>
+// DMA_AUX: the cache-policy operand of the K / V LDS-DMA.  2 = nt: a pair's K and V are read exactly once, by one CU.  Alone
+// on the chip the launch is 8 % faster with it (128.8 -> 118.3 us, tools/probe/attn_layout.hip -DATTN32_DMA_AUX=0|2); in the
+// tower it is 0.15 ms per forward SLOWER (36.70-36.79 -> 36.88-36.94 ms, one process): there K and V are warm from the
+// GEMM that wrote them 0.2 ms earlier, and nt gives up exactly that (MI355X_MICROARCH.md 'nt-weights': faster from cold caches,
+// slower replayed warm).  Option "attn_nt", default 0 (profiles/r06_attn_nt_probe.txt).  The query fragments go through the
+// same switch as __builtin_nontemporal_load.  Same values: same bits.
+template <int S_PAD, int S_CT, bool PRESCALED, int DMA_AUX = ATTN32_DMA_AUX>
 __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int S_rt,
                                                              int D, int H, int n_pairs, int cls_only, int force_shift,
                                                              int pair_order, int ld_qkv, int ld_ctx, uint32_t head_stride,
@@ -532,13 +541,17 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         unsigned char* Vd = Kd + S_PAD * 128;
         const uint32_t so = (uint32_t)(8 * j) * (uint32_t)(ld * 2);
         const uint32_t vo = (j & 1) ? voff1 : voff0;
-        glds16_buf(kr, vo, so, Kd + j * 1024);
-        glds16_buf(vr, vo, so, Vd + j * 1024);
+        glds16_buf_aux<DMA_AUX>(kr, vo, so, Kd + j * 1024);
+        glds16_buf_aux<DMA_AUX>(vr, vo, so, Vd + j * 1024);
+    };
+    auto ldq8 = [&](const bf16_t* p) {   // 8 query elements of one lane; read once: nt with the K / V stream
+        if constexpr (DMA_AUX & 2) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+        else return *reinterpret_cast<const bf16x8*>(p);
     };
     auto load_q_raw = [&](bf16x8 (&q)[4], const Pair& pr, int qrow) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            q[ks] = *reinterpret_cast<const bf16x8*>(pr.base + (size_t)qrow * ld + 16 * ks + 8 * h);
+            q[ks] = ldq8(pr.base + (size_t)qrow * ld + 16 * ks + 8 * h);
         }
     };
     auto scale_q = [&](bf16x8 (&q)[4]) {
@@ -629,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bf16_kernel(const bf16_t* __res
         auto dma_q_hook = [&](int step) {
             dma_hook();
             if (more && !q_at_top && step >= Q0 && step < Q0 + 4)
-                qa_n[step - Q0] = *reinterpret_cast<const bf16x8*>(nxt.base + (size_t)my_row * ld + 16 * (step - Q0) + 8 * h);
+                qa_n[step - Q0] = ldq8(nxt.base + (size_t)my_row * ld + 16 * (step - Q0) + 8 * h);
         };
         if (split && it > 0 && wave == 1) combine(scratch + (b ^ 1) * ATTN32_PART, ctx_prev);  // the previous pair's split query
         ATTN32_STAMP(2)

@@ -470,17 +470,20 @@ void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, 
             hipLaunchKernelGGL(attn_f32_kernel, dim3(blocks), dim3(64), 0, s, (const float*)qkv, (float*)ctx, m->S, m->D, m->H, m->text ? 1 : 0, first_tile_only ? 1 : 0);
         }
     } else if (attn32_applies(m)) {
+#define MI_ATTN32_L(SP, SC, PS, AUX)                                                                                   \
+    {                                                                                                                  \
+        static DevOnce once;                                                                                           \
+        allow_lds_once(once, attn32_bf16_kernel<SP, SC, PS, AUX>, LDS);                                                \
+        hipLaunchKernelGGL((attn32_bf16_kernel<SP, SC, PS, AUX>), dim3(grid), dim3(512), LDS, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, pairs, first_tile_only ? 1 : 0, m->attn_shift ? 1 : 0, m->attn_order, ld_qkv, m->D, head_stride, sel_stride); \
+    }
 #define MI_ATTN32(SP, SC)                                                                                              \
     {                                                                                                                  \
         constexpr int LDS = attn32_lds_bytes(SP);                                                                      \
-        static DevOnce once[2];                                                                                        \
         const int pairs = (int)(n * m->H), grid = std::min(pairs, m->n_cu);                                            \
         if (m->q_prescaled) {                                                                                          \
-            allow_lds_once(once[1], attn32_bf16_kernel<SP, SC, true>, LDS);                                            \
-            hipLaunchKernelGGL((attn32_bf16_kernel<SP, SC, true>), dim3(grid), dim3(512), LDS, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, pairs, first_tile_only ? 1 : 0, m->attn_shift ? 1 : 0, m->attn_order, ld_qkv, m->D, head_stride, sel_stride); \
+            if (m->attn_nt) MI_ATTN32_L(SP, SC, true, 2) else MI_ATTN32_L(SP, SC, true, 0)                             \
         } else {                                                                                                       \
-            allow_lds_once(once[0], attn32_bf16_kernel<SP, SC, false>, LDS);                                           \
-            hipLaunchKernelGGL((attn32_bf16_kernel<SP, SC, false>), dim3(grid), dim3(512), LDS, s, (const bf16_t*)qkv, (bf16_t*)ctx, m->S, m->D, m->H, pairs, first_tile_only ? 1 : 0, m->attn_shift ? 1 : 0, m->attn_order, ld_qkv, m->D, head_stride, sel_stride); \
+            if (m->attn_nt) MI_ATTN32_L(SP, SC, false, 2) else MI_ATTN32_L(SP, SC, false, 0)                           \
         }                                                                                                              \
     }
         if (m->S == 257) MI_ATTN32(288, 257)       // ViT-L/14, ViT-H/14 @224
@@ -489,6 +492,7 @@ void attention(mi_clip* m, const void* qkv, void* ctx, size_t n, hipStream_t s, 
         else if (m->S <= 224) MI_ATTN32(224, 0)
         else MI_ATTN32(288, 0)
 #undef MI_ATTN32
+#undef MI_ATTN32_L
     } else {
         if (m->q_prescaled) fail(MI_ERR_INVALID, "this handle's q weights carry the attn32 scale: attn_ver is fixed at load");
         const unsigned blocks = (unsigned)(n * m->H);
@@ -985,6 +989,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         if (k == "full_last") m->full_last = value != 0;
         else if (k == "attn_shift") m->attn_shift = value != 0;
         else if (k == "front_overlap") m->front_overlap = value != 0;
+        else if (k == "attn_nt") m->attn_nt = value != 0;
         else if (k == "qkv_pad") {   // the activation sets are sized by it: rebuild on next use
             if (value < 0 || value > 1024 || value % 64) fail(MI_ERR_INVALID, "qkv_pad must be a multiple of 64 in 0..1024");
             if (m->text) fail(MI_ERR_INVALID, "the text tower's qkv rows are dense");
@@ -1032,7 +1037,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, front_overlap, attn_shift, attn_order, qkv_pad, qkv_layout, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, text_fuse, attn_f32_mfma, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, front_overlap, attn_shift, attn_nt, attn_order, qkv_pad, qkv_layout, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, text_fuse, attn_f32_mfma, max_batch, parts)", key);
     });
 }
 
@@ -1479,6 +1484,7 @@ int mi_op_attention(int device, int precision, const float* qkv, float* ctx, siz
         if (const char* e = std::getenv("MI_OP_ATTN")) m.attn_ver = std::atoi(e) == 1 ? 1 : 2;   // test hook: which bf16 kernel
         if (const char* e = std::getenv("MI_OP_ATTN_SHIFT")) m.attn_shift = std::atoi(e) != 0;
         if (const char* e = std::getenv("MI_OP_ATTN_ORDER")) m.attn_order = std::atoi(e) != 0;   // test hook: first pair of a workgroup
+        if (const char* e = std::getenv("MI_OP_ATTN_NT")) m.attn_nt = std::atoi(e) != 0;         // test hook: cache policy of the K / V / q stream
         if (const char* e = std::getenv("MI_OP_ATTN_F32_MFMA")) m.attn_f32_mfma = std::atoi(e) != 0;   // test hook: 0 = the one-thread-per-query fp32 kernel
         const size_t rows = n_img * s_tok;
         void* dq = sc.up(precision, qkv, rows, 3 * (size_t)d, pad256(rows));

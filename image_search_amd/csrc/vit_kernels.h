@@ -1102,6 +1102,12 @@ __device__ __forceinline__ void glds16_buf(rsrc_t r, uint32_t voff, uint32_t sof
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff,
                                              0, 0);
 }
+// the same with a cache-policy operand (AUX = 2: nt, for bytes ONE CU reads once)
+template <int AUX>
+__device__ __forceinline__ void glds16_buf_aux(rsrc_t r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff,
+                                             0, AUX);
+}
 
 
 // ------------------------------------------------------------------ the residual stream of the LayerNorm-free tower

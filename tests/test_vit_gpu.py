@@ -219,10 +219,14 @@ def test_attention32_row_pitch_and_pair_order_do_not_change_a_bit(built, monkeyp
     # the next image's rows lie right behind it and NaN patterns behind the last one — rows >= S must still read as zeros
     monkeypatch.delenv("MI_OP_ATTN_QKV_PAD")
     monkeypatch.setenv("MI_OP_ATTN_LAYOUT", "1")
-    for order in (0, 1):
+    for order, nt in ((0, 1), (1, 1), (1, 0)):
         monkeypatch.setenv("MI_OP_ATTN_ORDER", str(order))
+        monkeypatch.setenv("MI_OP_ATTN_NT", str(nt))   # the cache policy of the K / V / q stream: a hint, never a value
         got = ops.attention(qkv, H, PRECISION_BF16)
-        assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), ("planes", order)
+        assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), ("planes", order, nt)
+    monkeypatch.delenv("MI_OP_ATTN_LAYOUT")
+    monkeypatch.setenv("MI_OP_ATTN_NT", "0")
+    assert np.array_equal(ops.attention(qkv, H, PRECISION_BF16).view(np.uint32), base.view(np.uint32)), "rows, default cache policy"
 
 
 @pytest.mark.parametrize("prec,tol", [(PRECISION_F32, 2e-6), (PRECISION_BF16, 5e-3)])
@@ -561,11 +565,15 @@ def test_ab_hooks_of_the_bf16_tower_do_not_change_a_bit(l14, ln_fold):
         m.set_option("qkv_layout", layout)
         m.set_option("attn_order", order)
         m.set_option("split_tail", split)
+        m.set_option("attn_nt", split)   # nt or default cache policy on attention's K / V / q stream
         assert np.array_equal(m.forward(px).view(np.uint32), ref.view(np.uint32)), ("layout", layout, order, split)
         assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32)), ("layout", layout, order, split)
         assert np.array_equal(m.forward(px41[:3]).view(np.uint32), ref41[:3].view(np.uint32)), ("layout, one stream", layout)
     m.set_option("full_last", 1)
     assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32))
+    m.set_option("attn_nt", 0)
+    assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32))
+    m.set_option("attn_nt", 1)
     m.set_option("qkv_layout", 0)
     m.set_option("qkv_pad", 64)
     assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32))
