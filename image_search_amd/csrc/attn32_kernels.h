@@ -439,7 +439,11 @@ __device__ __forceinline__ void attn32_store(const v16f (&o)[2], float inv, bf16
             const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
             v4u d;
             d.x = rx[0]; d.y = ry[0]; d.z = rx[1]; d.w = ry[1];
+#ifdef ATTN32_STORE_NT   // probe builds: the context rows (read next by out_proj) with the nt policy
+            if (valid) __builtin_nontemporal_store(d, reinterpret_cast<v4u*>(ctx_b + (size_t)qrow * D + 32 * dt + 16 * kk + 8 * h));
+#else
             if (valid) *reinterpret_cast<v4u*>(ctx_b + (size_t)qrow * D + 32 * dt + 16 * kk + 8 * h) = d;
+#endif
         }
 }
 

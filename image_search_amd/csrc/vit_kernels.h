@@ -1098,6 +1098,33 @@ __device__ __forceinline__ void buffer_store_b128(v4u d, rsrc_t r, uint32_t voff
     __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 0);
     asm volatile("s_nop 1" :: "v"(d) : "memory");
 }
+// ... with a cache-policy operand (2 = nt).  The persistent GEMM's outputs are written once and read by a LATER kernel, while
+// the operands it streams (an XCD's 6 MB of X panels and W tiles per round of tiles) live in a 4 MB L2: output lines
+// allocated there push operands out.  Which epilogue stores carry nt is set per kind below; probe builds override the
+// macros (tools/tower_ab.py --lib, profiles/r06_store_policy_ab.txt).
+#ifndef MI_PP_STORE_AUX_QKV
+#define MI_PP_STORE_AUX_QKV 2   // EPI_BIAS / EPI_LNF outputs: q|k|v (read by attention), the LayerNorm tower's deltas
+#endif
+#ifndef MI_PP_STORE_AUX_H
+#define MI_PP_STORE_AUX_H 2     // EPI_*_QGELU outputs: h (read by fc2)
+#endif
+#ifndef MI_PP_RES_LOAD_AUX
+#define MI_PP_RES_LOAD_AUX 0    // EPI_RESID24: the loads of the old planes (read once, then rewritten in place)
+#endif
+#ifndef MI_PP_X_AUX
+#define MI_PP_X_AUX 0           // the X operand's LDS-DMA (probe: would evict-first X lines leave the W tiles in L2 across rounds?)
+#endif
+#ifndef MI_PP_W_AUX
+#define MI_PP_W_AUX 0           // the W operand's LDS-DMA
+#endif
+#ifndef MI_PP_STORE_AUX_RES
+#define MI_PP_STORE_AUX_RES 0   // EPI_RESID24: the residual planes, rewritten in place
+#endif
+template <int AUX>
+__device__ __forceinline__ void buffer_store_b128_aux(v4u d, rsrc_t r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, AUX);
+    asm volatile("s_nop 1" :: "v"(d) : "memory");
+}
 __device__ __forceinline__ void glds16_buf(rsrc_t r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff,
                                              0, 0);
@@ -1253,8 +1280,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
         const int h = (j >= 2) ? 1 : 0;
         unsigned char* dst = smem + buf * 65536 + (is_x ? 0 : 32768) + h * 16384 + wave * 2048;
         const uint32_t so = (is_x ? xs + x_wave + 64u * h * Kb : ws + w_wave + 32u * h * Kb) + (uint32_t)kt * 128u;
-        glds16_buf(is_x ? xr : wr, x_lane, so, dst);
-        glds16_buf(is_x ? xr : wr, x_lane, so + 8u * Kb, dst + 1024);
+        if (is_x) {
+            glds16_buf_aux<MI_PP_X_AUX>(xr, x_lane, so, dst);
+            glds16_buf_aux<MI_PP_X_AUX>(xr, x_lane, so + 8u * Kb, dst + 1024);
+        } else {
+            glds16_buf_aux<MI_PP_W_AUX>(wr, x_lane, so, dst);
+            glds16_buf_aux<MI_PP_W_AUX>(wr, x_lane, so + 8u * Kb, dst + 1024);
+        }
     };
     unsigned char* bias_lds = smem + 131072 + 18432 + wave * AUX;
     const rsrc_t cr = make_rsrc(LNF ? fold.cvec : bias, (uint32_t)N * 4u);
@@ -1365,8 +1397,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
         float ks[4] = {0.0f, 0.0f, 0.0f, 0.0f}, kq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         auto fetch = [&](int st) {   // old planes of step st = (mi, j): rows mi * 16 + j * 8 + (lane >> 3)
             const uint32_t so = o_tile + (uint32_t)((st >> 1) * 16 + (st & 1) * 8) * (uint32_t)ldo * 2u;
-            hq[st % RES_P] = __builtin_amdgcn_raw_buffer_load_b128(orr, o_lane, so, 0);
-            lq[st % RES_P] = __builtin_amdgcn_raw_buffer_load_b64(lor, o_lane >> 1, so >> 1, 0);
+            hq[st % RES_P] = __builtin_amdgcn_raw_buffer_load_b128(orr, o_lane, so, MI_PP_RES_LOAD_AUX);
+            lq[st % RES_P] = __builtin_amdgcn_raw_buffer_load_b64(lor, o_lane >> 1, so >> 1, MI_PP_RES_LOAD_AUX);
         };
         if constexpr (RES) {   // in step order: the first wait must not stand behind the whole burst
 #pragma unroll
@@ -1408,8 +1440,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
                     v4u hn; v2u ln; float S, Q;
                     resid24_step(hq[st % RES_P], lq[st % RES_P], d, hn, ln, S, Q);
                     __builtin_amdgcn_sched_barrier(0);
-                    buffer_store_b128(hn, orr, o_lane, so);
-                    __builtin_amdgcn_raw_buffer_store_b64(ln, lor, o_lane >> 1, so >> 1, 0);
+                    buffer_store_b128_aux<MI_PP_STORE_AUX_RES>(hn, orr, o_lane, so);
+                    __builtin_amdgcn_raw_buffer_store_b64(ln, lor, o_lane >> 1, so >> 1, MI_PP_STORE_AUX_RES);
                     if (st + RES_P < 16) fetch(st + RES_P);
                     S += dpp_movf<0xB1>(S); Q += dpp_movf<0xB1>(Q);   // the four lanes of a 32-column block
                     S += dpp_movf<0x4E>(S); Q += dpp_movf<0x4E>(Q);
@@ -1421,7 +1453,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("" :: "v"(hn), "v"(ln));
                 } else {
-                    buffer_store_b128(d, orr, o_lane, so);
+                    buffer_store_b128_aux<GELU ? MI_PP_STORE_AUX_H : MI_PP_STORE_AUX_QKV>(d, orr, o_lane, so);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1520,10 +1552,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
         unsigned char* dx = smem + (slot & 1) * 65536 + (slot >> 1) * 16384 + wave * 2048;
         unsigned char* dw = dx + 32768;
         const uint32_t sx = xs + x_wave + (uint32_t)kt * 128u, sw = ws + w_wave + (uint32_t)kt * 128u;
-        glds16_buf(xr, x_lane, sx, dx);
-        glds16_buf(xr, x_lane, sx + 8u * Kb, dx + 1024);
-        glds16_buf(wr, x_lane, sw, dw);
-        glds16_buf(wr, x_lane, sw + 8u * Kb, dw + 1024);
+        glds16_buf_aux<MI_PP_X_AUX>(xr, x_lane, sx, dx);
+        glds16_buf_aux<MI_PP_X_AUX>(xr, x_lane, sx + 8u * Kb, dx + 1024);
+        glds16_buf_aux<MI_PP_W_AUX>(wr, x_lane, sw, dw);
+        glds16_buf_aux<MI_PP_W_AUX>(wr, x_lane, sw + 8u * Kb, dw + 1024);
     };
     for (int task = lb; task < n_tasks; task += G) {
         const int t = n_full + (task >> 2), mh = (task >> 1) & 1, nh = task & 1;
@@ -1564,8 +1596,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const uint32_t so = q_tile + (uint32_t)(mi * 16) * (uint32_t)ldo * 2u;
-                hq[mi] = __builtin_amdgcn_raw_buffer_load_b128(orr, q_lane, so, 0);
-                lq[mi] = __builtin_amdgcn_raw_buffer_load_b64(lor, q_lane >> 1, so >> 1, 0);
+                hq[mi] = __builtin_amdgcn_raw_buffer_load_b128(orr, q_lane, so, MI_PP_RES_LOAD_AUX);
+                lq[mi] = __builtin_amdgcn_raw_buffer_load_b64(lor, q_lane >> 1, so >> 1, MI_PP_RES_LOAD_AUX);
             }
         }
 #pragma unroll
@@ -1600,8 +1632,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
                 v4u hn; v2u ln; float S, Q;
                 resid24_step(hq[mi], lq[mi], d, hn, ln, S, Q);
                 __builtin_amdgcn_sched_barrier(0);
-                buffer_store_b128(hn, orr, q_lane, so);
-                __builtin_amdgcn_raw_buffer_store_b64(ln, lor, q_lane >> 1, so >> 1, 0);
+                buffer_store_b128_aux<MI_PP_STORE_AUX_RES>(hn, orr, q_lane, so);
+                __builtin_amdgcn_raw_buffer_store_b64(ln, lor, q_lane >> 1, so >> 1, MI_PP_STORE_AUX_RES);
                 S += dpp_movf<0xB1>(S); Q += dpp_movf<0xB1>(Q);
                 S += dpp_movf<0x4E>(S); Q += dpp_movf<0x4E>(Q);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1611,7 +1643,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
                 const v2u pv = {__float_as_uint(S), __float_as_uint(Q)};
                 if (t4 == 0) __builtin_amdgcn_raw_buffer_store_b64(pv, pr, (prow * (uint32_t)nslot + (uint32_t)(ttn * 8 + wn * 2 + nh)) * 8u, 0, 0);
             } else {
-                buffer_store_b128(d, orr, q_lane, so);
+                buffer_store_b128_aux<GELU ? MI_PP_STORE_AUX_H : MI_PP_STORE_AUX_QKV>(d, orr, q_lane, so);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);

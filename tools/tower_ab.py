@@ -11,6 +11,9 @@ import json, os, sys, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if "--lib" in sys.argv:   # a probe build of the library (e.g. another cache policy compiled in): A/B across processes on one box
+    from image_search_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from image_search_amd import synth
 from image_search_amd.clip import Model, PRECISION_BF16
 
@@ -19,6 +22,7 @@ DEFAULTS = {"ln_fold": 1, "ln_nt": 0, "split_tail": 1, "parts": 2, "x24": 1, "ge
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    lib_note = sys.argv[sys.argv.index("--lib") + 1] if "--lib" in sys.argv else "image_search_amd/libmi355clip.so"
     def flag(name, dflt):
         return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else dflt
     args = [a for a in args if "=" in a] or ["ln_fold=0", "ln_fold=1"]
@@ -63,7 +67,7 @@ def main():
                "bit_equal_to_first": bool((outs[v].view(np.uint32) == ref.view(np.uint32)).all()),
                "max_diff_to_first_over_rms": float(np.abs(outs[v] - ref).max() / np.sqrt((ref.astype(np.float64) ** 2).mean())),
                "finite": bool(np.isfinite(outs[v]).all())} for v in args}
-    print(json.dumps({"n": n, "reps": reps, "variants": res}))
+    print(json.dumps({"n": n, "reps": reps, "lib": lib_note, "variants": res}))
 
 
 if __name__ == "__main__":
