@@ -100,6 +100,7 @@ struct mi_clip {
     int qkv_pad = 128;        // elements added to the image tower's qkv row pitch where attn32 runs (vit.hip: qkv_pitch)
     int qkv_layout = 0;       // 0 = token rows [M][3D + pad]; 1 = head-major planes [3][H][Mp][64] (vit.hip: qkv_head_major)
     bool front_overlap = false; // mi_pipeline_ingest / mi_clip_embed: a forward's patch gather + patch GEMM on the copy stream, under the previous forward (option "front_overlap")
+    bool store_nt = true;     // persistent GEMM: q|k|v / h / delta stores with the nt cache policy (outputs a later kernel reads; -0.25..-0.45 ms per forward); option "store_nt"
     bool attn_nt = false;     // attn32: K / V LDS-DMA and query loads with the nt cache policy (read once by one CU); option "attn_nt": -8 % alone, +0.15 ms in the tower (its K / V are warm from the GEMM that wrote them): off
     int attn_order = 1;       // attn32: first pair of workgroup b (0 = b; 1 = transposed, an XCD's workgroups spread over all heads)
     bool full_last = false;   // compute the dead rows of the last layer too (A/B against the reference graph)

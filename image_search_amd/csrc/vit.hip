@@ -375,9 +375,6 @@ void launch_pp(mi_clip* m, const void* X, const void* W, const float* bias, void
                const PpFold& fold, hipStream_t s) {
     constexpr bool LNF = EPI == EPI_LNF || EPI == EPI_LNF_QGELU;
     constexpr int LDS = 131072 + 18432 + 8 * (LNF ? 1536 : 256);
-    auto kern = gemm_bf16_pp_kernel<EPI, bf16_t>;
-    static DevOnce once;
-    allow_lds_once(once, kern, LDS);
     const int n_tiles = (int)((Mp / 256) * (N / 256));
     const int grid = std::min(n_tiles * 4, m->n_cu);
     // a short last round (<= a quarter of the CUs busy) is cut into quadrant tasks
@@ -386,8 +383,20 @@ void launch_pp(mi_clip* m, const void* X, const void* W, const float* bias, void
     const int nt = N / 256;
     auto fits = [&](int np) { return np > 0 && nt > np && nt % np == 0; };
     const int order = fits(m->gemm_order) ? m->gemm_order : (m->gemm_order > 0 && fits(4)) ? 4 : 0;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, (int)Mp, N, K, ldo,
-                       n_tiles, n_full, order, fold);
+    // option "store_nt" (default 1): the plain output stores with the nt cache policy; EPI_RESID24 has none of them
+    if (EPI == EPI_RESID24 || m->store_nt) {
+        auto kern = gemm_bf16_pp_kernel<EPI, bf16_t, true>;
+        static DevOnce once;
+        allow_lds_once(once, kern, LDS);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, (int)Mp, N, K, ldo,
+                           n_tiles, n_full, order, fold);
+    } else {
+        auto kern = gemm_bf16_pp_kernel<EPI, bf16_t, (EPI == EPI_RESID24)>;
+        static DevOnce once;
+        allow_lds_once(once, kern, LDS);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, (const bf16_t*)X, (const bf16_t*)W, bias, out, (int)Mp, N, K, ldo,
+                           n_tiles, n_full, order, fold);
+    }
     HIP_CHECK(hipGetLastError());
 }
 
@@ -990,6 +999,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
         else if (k == "attn_shift") m->attn_shift = value != 0;
         else if (k == "front_overlap") m->front_overlap = value != 0;
         else if (k == "attn_nt") m->attn_nt = value != 0;
+        else if (k == "store_nt") m->store_nt = value != 0;
         else if (k == "qkv_pad") {   // the activation sets are sized by it: rebuild on next use
             if (value < 0 || value > 1024 || value % 64) fail(MI_ERR_INVALID, "qkv_pad must be a multiple of 64 in 0..1024");
             if (m->text) fail(MI_ERR_INVALID, "the text tower's qkv rows are dense");
@@ -1037,7 +1047,7 @@ int mi_clip_set_option(mi_clip* m, const char* key, int value) {
                 m->cap = 0;
                 m->parts = value;
             }
-        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, front_overlap, attn_shift, attn_nt, attn_order, qkv_pad, qkv_layout, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, text_fuse, attn_f32_mfma, max_batch, parts)", key);
+        } else fail(MI_ERR_INVALID, "unknown option '%s' (full_last, front_overlap, attn_shift, attn_nt, store_nt, attn_order, qkv_pad, qkv_layout, split_tail, gemm_order, im2col_rows, ln_nt, x24, ln_fold, text_fast, text_fuse, attn_f32_mfma, max_batch, parts)", key);
     });
 }
 
@@ -1395,6 +1405,7 @@ void op_pp_model(mi_clip& mm, int device) {
     if (const char* e = std::getenv("MI_OP_GRID")) mm.n_cu = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("MI_OP_GEMM_ORDER")) mm.gemm_order = std::max(0, std::min(16, std::atoi(e)));
     if (const char* e = std::getenv("MI_GEMM_SPLIT")) mm.split_tail = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MI_OP_STORE_NT")) mm.store_nt = std::atoi(e) != 0;   // test hook: cache policy of the output stores
 }
 }  // namespace
 

@@ -1240,7 +1240,9 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
 #define PP_CLOCK_BEGIN
 #define PP_CLOCK_END
 #endif
-template <int EPI, typename TO>
+// STORE_NT: the plain output stores (every epilogue but EPI_RESID24) carry the nt cache policy (MI_PP_STORE_AUX_* above);
+// 0 = default policy, the A/B partner of option "store_nt".
+template <int EPI, typename TO, bool STORE_NT = true>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ X,
                                                               const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias,
@@ -1453,7 +1455,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("" :: "v"(hn), "v"(ln));
                 } else {
-                    buffer_store_b128_aux<GELU ? MI_PP_STORE_AUX_H : MI_PP_STORE_AUX_QKV>(d, orr, o_lane, so);
+                    buffer_store_b128_aux<STORE_NT ? (GELU ? MI_PP_STORE_AUX_H : MI_PP_STORE_AUX_QKV) : 0>(d, orr, o_lane, so);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1643,7 +1645,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const bf16_t* __re
                 const v2u pv = {__float_as_uint(S), __float_as_uint(Q)};
                 if (t4 == 0) __builtin_amdgcn_raw_buffer_store_b64(pv, pr, (prow * (uint32_t)nslot + (uint32_t)(ttn * 8 + wn * 2 + nh)) * 8u, 0, 0);
             } else {
-                buffer_store_b128_aux<GELU ? MI_PP_STORE_AUX_H : MI_PP_STORE_AUX_QKV>(d, orr, q_lane, so);
+                buffer_store_b128_aux<STORE_NT ? (GELU ? MI_PP_STORE_AUX_H : MI_PP_STORE_AUX_QKV) : 0>(d, orr, q_lane, so);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);

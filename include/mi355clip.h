@@ -116,6 +116,9 @@ int mi_weights_list(const char* weights_path, char* buf, size_t cap, size_t* nee
  *   "qkv_layout" how the bf16 image tower keeps q|k|v between the q/k/v GEMM and the persistent attention: 0 = token rows
  *                [M][3 D + qkv_pad]; 1 = head-major planes [3][H][Mp][64] (the GEMM's epilogue stores one contiguous KiB per
  *                wave-instruction, attention fetches a head's K / V / q of one image as one contiguous block).  Same bits
+ *   "store_nt"   1 (default) = the persistent GEMM writes q|k|v, h and the deltas — outputs a LATER kernel reads — with the nt cache
+ *                policy, so that they do not take the XCDs' L2 lines from the operands the same launch streams: - 0.25 ... - 0.45 ms
+ *                per 256-image forward; 0 = default policy (A/B hook).  Same bits
  *   "attn_nt"    1 = the persistent attention fetches K, V and q — each read exactly once, by one CU — with the nt cache policy
  *                (A/B hook, default 0: the kernel alone is 8 % faster with it, the tower 0.4 % slower — its K / V are still warm
  *                from the GEMM that wrote them).  Same bits

@@ -566,14 +566,17 @@ def test_ab_hooks_of_the_bf16_tower_do_not_change_a_bit(l14, ln_fold):
         m.set_option("attn_order", order)
         m.set_option("split_tail", split)
         m.set_option("attn_nt", split)   # nt or default cache policy on attention's K / V / q stream
+        m.set_option("store_nt", order)  # ... and on the persistent GEMM's q|k|v / h stores (default 1)
         assert np.array_equal(m.forward(px).view(np.uint32), ref.view(np.uint32)), ("layout", layout, order, split)
         assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32)), ("layout", layout, order, split)
         assert np.array_equal(m.forward(px41[:3]).view(np.uint32), ref41[:3].view(np.uint32)), ("layout, one stream", layout)
     m.set_option("full_last", 1)
     assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32))
     m.set_option("attn_nt", 0)
+    m.set_option("store_nt", 0)
     assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32))
     m.set_option("attn_nt", 1)
+    m.set_option("store_nt", 1)
     m.set_option("qkv_layout", 0)
     m.set_option("qkv_pad", 64)
     assert np.array_equal(m.forward(px41).view(np.uint32), ref41.view(np.uint32))

@@ -17,7 +17,7 @@ if "--lib" in sys.argv:   # a probe build of the library (e.g. another cache pol
 from image_search_amd import synth
 from image_search_amd.clip import Model, PRECISION_BF16
 
-DEFAULTS = {"ln_fold": 1, "ln_nt": 0, "split_tail": 1, "parts": 2, "x24": 1, "gemm_order": 4, "qkv_pad": 128, "attn_order": 1, "qkv_layout": 0, "attn_nt": 0}
+DEFAULTS = {"ln_fold": 1, "ln_nt": 0, "split_tail": 1, "parts": 2, "x24": 1, "gemm_order": 4, "qkv_pad": 128, "attn_order": 1, "qkv_layout": 0, "attn_nt": 0, "store_nt": 1}
 
 
 def main():
